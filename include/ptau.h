@@ -1,0 +1,145 @@
+/* ptau.h — C ABI of the MI355X-native chunked powers-of-tau engine (libptau_hip.so).
+ *
+ * Drop-in boundary for the ONE hot path of nimiq/snark-setup-operator: the per-chunk phase-1
+ * tau-update and its verification.  Each entry point names the reference interface it replaces
+ * (file:line in /root/reference; the bodies live in the un-vendored crates phase1-cli / phase1 /
+ * setup-utils @ nimiq/snark-setup bd530da — SURVEY.md §8).  INTEGRATION.md shows the Rust
+ * `extern "C"` binding a maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; the library never retains a caller pointer after return;
+ *   - scalars (tau, alpha, beta, coefficients) are CANONICAL (non-Montgomery) little-endian
+ *     64-bit limbs, ptau_fr_limbs(curve) of them  (= ark-ff BigInt<N>.0);
+ *   - byte formats are arkworks-0.4 canonical serialisation;
+ *   - return 0 on success, a negative PTAU_E_* code otherwise; a message is copied into the
+ *     caller's `err` buffer when one is given.  Nothing aborts, exits or throws across the ABI:
+ *     the Rust shim turns a non-zero code into `panic!(msg)` inside `spawn_quiet`, preserving the
+ *     reference's error behaviour (src/bin/contribute.rs:809-856);
+ *   - `device` is the HIP device ordinal (the operator's task index % ngpu,
+ *     src/bin/contribute.rs:245-250).  Calls on distinct devices may run concurrently; calls on
+ *     one device are serialised internally.
+ *   - There is NO CPU fallback: every compute entry point fails with PTAU_E_DEVICE when no
+ *     gfx950 device is usable.
+ */
+#ifndef PTAU_H
+#define PTAU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* curve_kind dispatch — src/bin/contribute.rs:1156-1211, src/bin/verify_transcript.rs:876-887 */
+enum { PTAU_CURVE_BLS12_377 = 0, PTAU_CURVE_BW6_761 = 1, PTAU_CURVE_MNT4_753 = 2, PTAU_CURVE_MNT6_753 = 3 };
+enum { PTAU_G1 = 1, PTAU_G2 = 2 };
+/* phase1::ContributionMode / ProvingSystem — src/utils.rs:326-352 */
+enum { PTAU_MODE_CHUNKED = 0, PTAU_MODE_FULL = 1 };
+enum { PTAU_PROVING_GROTH16 = 0, PTAU_PROVING_MARLIN = 1 };
+/* setup_utils::CheckForCorrectness — src/bin/contribute.rs:38-43,816-819,971-980 */
+enum { PTAU_CHECK_NO = 0, PTAU_CHECK_ONLY_NON_ZERO = 1, PTAU_CHECK_ONLY_IN_GROUP = 2, PTAU_CHECK_FULL = 3 };
+/* setup_utils::SubgroupCheckMode — src/bin/contribute.rs:140-145 */
+enum { PTAU_SUBGROUP_AUTO = 0, PTAU_SUBGROUP_DIRECT = 1, PTAU_SUBGROUP_BATCHED = 2, PTAU_SUBGROUP_NO = 3 };
+/* setup_utils::BatchExpMode — src/bin/contribute.rs:134-139 (all values run the same GPU path) */
+enum { PTAU_BATCH_EXP_AUTO = 0, PTAU_BATCH_EXP_DIRECT = 1, PTAU_BATCH_EXP_BATCH_INVERSION = 2 };
+
+enum {
+    PTAU_OK = 0,
+    PTAU_E_ARG = -1,               /* bad enum / null pointer */
+    PTAU_E_LEN = -2,               /* buffer length != accumulator_size / contribution_size */
+    PTAU_E_POINT = -3,             /* non-canonical coordinate or x not on the curve */
+    PTAU_E_POINT_AT_INFINITY = -4, /* CheckForCorrectness::OnlyNonZero / Full */
+    PTAU_E_NOT_IN_SUBGROUP = -5,   /* CheckForCorrectness::OnlyInGroup / Full, subgroup check */
+    PTAU_E_INVALID_RATIO = -6,     /* check_same_ratio failed */
+    PTAU_E_HASH_CHAIN = -7,        /* response[0..64) != BLAKE2b(challenge) */
+    PTAU_E_DEVICE = -8,            /* no usable gfx950 device / HIP error */
+    PTAU_E_IO = -9,                /* file open / size / create_new failure */
+    PTAU_E_UNSUPPORTED = -10       /* e.g. Marlin geometry */
+};
+
+/* The ceremony `Parameters` JSON (src/data_structs.rs:123-131) + chunk index:
+ * what create_parameters_for_chunk / create_full_parameters consume (src/utils.rs:326-352). */
+typedef struct ptau_params {
+    int32_t curve;             /* PTAU_CURVE_* */
+    int32_t proving_system;    /* PTAU_PROVING_* */
+    int32_t contribution_mode; /* PTAU_MODE_* */
+    uint32_t power;
+    uint64_t chunk_index;
+    uint64_t chunk_size;
+    uint64_t batch_size;
+} ptau_params;
+
+/* Fields of Phase1Parameters the reference reads (src/bin/new_setup.rs:274-277, src/utils.rs:526-532). */
+typedef struct ptau_sizes {
+    uint64_t powers_length, powers_g1_length;
+    uint64_t g1_chunk_size, other_chunk_size;
+    uint64_t accumulator_size, contribution_size, public_key_size, hash_size;
+    uint64_t start; /* global exponent index of element 0 */
+} ptau_sizes;
+
+/* Per-call device timings (HIP events on the library's stream), for the reference's
+ * contribution_duration accounting (src/bin/contribute.rs:857-870) and bench.py. */
+typedef struct ptau_timing {
+    double h2d_ms, kernel_ms, d2h_ms; /* summed over the call */
+    double scalar_mul_ms, normalize_ms; /* the two kernels of the tau-update */
+    uint64_t points;                  /* group elements processed */
+} ptau_timing;
+
+const char *ptau_strerror(int code);
+int ptau_device_count(void);
+/* Device name / CU count for processor_data (src/bin/contribute.rs:858-864). */
+int ptau_device_info(int device, char *name, size_t name_len, int *compute_units, uint64_t *hbm_bytes);
+
+/* Phase1Parameters::{new_chunk,new_full} geometry — src/utils.rs:326-352 */
+int ptau_params_sizes(const ptau_params *p, ptau_sizes *out);
+int ptau_point_size(int curve, int group, int compressed);
+int ptau_fr_limbs(int curve);
+
+/* setup_utils::calculate_hash — src/bin/verify_transcript.rs:344-345, src/utils.rs:618-623 (host CPU) */
+void ptau_blake2b512(const uint8_t *data, size_t len, uint8_t out[64]);
+
+/* setup-utils apply_powers = read_batch -> generate_powers_of_tau -> batch_exp -> write_batch
+ * (inside phase1_cli::contribute, src/bin/contribute.rs:811-823):
+ *     out[i] = (coeff * tau^(start+i)) * in[i],  i in [0, n)
+ * `in`/`out` are HOST buffers of n serialized points. coeff may be NULL. */
+int ptau_apply_powers(int curve, int group, const uint8_t *in, int compressed_in, uint8_t *out,
+                      int compressed_out, uint64_t n, uint64_t start, const uint64_t *tau,
+                      const uint64_t *coeff, int check_input, int device, char *err, size_t err_len);
+
+/* Same, on DEVICE-resident buffers (hipMalloc / torch CUDA tensors): the kernel-only path
+ * bench.py times.  Runs on the library's stream for `device` and synchronises before returning. */
+int ptau_apply_powers_dev(int curve, int group, const void *d_in, int compressed_in, void *d_out,
+                          int compressed_out, uint64_t n, uint64_t start, const uint64_t *tau,
+                          const uint64_t *coeff, int check_input, int device, char *err, size_t err_len);
+
+/* Phase1::computation — inside phase1_cli::contribute (src/bin/contribute.rs:811-823):
+ * `in` = whole challenge (accumulator_size, uncompressed), `out` = whole response buffer
+ * (contribution_size); fills out[64 .. contribution_size - public_key_size).  The host keeps
+ * hashing, key generation and the public-key write. */
+int ptau_phase1_computation(const ptau_params *p, const uint8_t *in, size_t in_len, uint8_t *out,
+                            size_t out_len, const uint64_t *tau, const uint64_t *alpha,
+                            const uint64_t *beta, int check_input, int device, char *err, size_t err_len);
+
+/* phase1_cli::contribute with the key pair as INPUT (key generation stays on the Rust host,
+ * SURVEY §8 a5) — src/bin/contribute.rs:811-823.  Reads `challenge_path` (must be exactly
+ * accumulator_size), writes challenge_hash_path (64 raw bytes), creates response_path
+ * (create_new semantics) = hash(challenge) | updated elements | public_key, writes
+ * response_hash_path. */
+int ptau_contribute_file(const ptau_params *p, const char *challenge_path, const char *challenge_hash_path,
+                         const char *response_path, const char *response_hash_path, const uint64_t *tau,
+                         const uint64_t *alpha, const uint64_t *beta, const uint8_t *public_key,
+                         size_t public_key_len, int check_input, int batch_exp_mode, int device, char *err,
+                         size_t err_len);
+
+/* Phase1::decompress for one vector — inside phase1_cli::transform_pok_and_correctness
+ * (src/bin/contribute.rs:968-986): n compressed points -> n uncompressed points (host buffers). */
+int ptau_decompress(int curve, int group, const uint8_t *in, uint8_t *out, uint64_t n, int check_output,
+                    int device, char *err, size_t err_len);
+
+/* Timings of the most recent compute call on `device`. */
+int ptau_last_timing(int device, ptau_timing *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTAU_H */

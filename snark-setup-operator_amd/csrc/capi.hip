@@ -1,0 +1,520 @@
+// C ABI of libptau_hip.so (include/ptau.h): host orchestration of the HIP kernels.
+//
+// Host-side equivalent of the phase1-cli / phase1 drivers the operator calls
+// (/root/reference/src/bin/contribute.rs:811-823, 968-986; src/utils.rs:326-352): chunk geometry,
+// buffer split, per-vector kernel launches, BLAKE2b hash chain, file-level contribute.
+// No CPU compute fallback exists: without a usable device every compute call fails.
+#include <hip/hip_runtime.h>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cerrno>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/ptau.h"
+#include "kernels_impl.hpp"
+
+namespace {
+
+using ptau::GroupOps;
+
+struct Err {
+    char *buf;
+    size_t len;
+    int fail(int code, const char *fmt, ...) const {
+        if (buf && len) {
+            va_list ap;
+            va_start(ap, fmt);
+            vsnprintf(buf, len, fmt, ap);
+            va_end(ap);
+        }
+        return code;
+    }
+};
+
+const GroupOps *get_ops(int curve, int group) {
+    switch (curve) {
+    case PTAU_CURVE_BLS12_377: return ptau::ops_bls12_377(group);
+    case PTAU_CURVE_BW6_761: return ptau::ops_bw6_761(group);
+    case PTAU_CURVE_MNT4_753: return ptau::ops_mnt4_753(group);
+    case PTAU_CURVE_MNT6_753: return ptau::ops_mnt6_753(group);
+    }
+    return nullptr;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return err.fail(PTAU_E_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_));         \
+    } while (0)
+
+constexpr int MAX_DEVICES = 16;
+constexpr uint64_t MAX_LAUNCH_POINTS = 1ull << 20;   // points per kernel launch (scratch sizing)
+constexpr uint64_t NORMALIZE_GROUP = 32;             // points per inversion in normalize_kernel
+
+struct DeviceCtx {
+    std::mutex mu;
+    bool ready = false;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[6] = {};
+    void *scratch = nullptr, *pre = nullptr;
+    size_t scratch_cap = 0, pre_cap = 0;
+    uint32_t *d_table = nullptr;   // scalar table (65 entries x 24 limbs max)
+    int *d_err = nullptr;
+    void *d_in = nullptr, *d_out = nullptr;   // staging for the host-buffer entry points
+    size_t in_cap = 0, out_cap = 0;
+    ptau_timing timing = {};
+};
+DeviceCtx g_ctx[MAX_DEVICES];
+
+int ensure_ctx(int device, DeviceCtx *&c, const Err &err) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return err.fail(PTAU_E_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= n || device >= MAX_DEVICES)
+        return err.fail(PTAU_E_DEVICE, "device ordinal %d out of range (%d devices)", device, n);
+    c = &g_ctx[device];
+    HIP_TRY(hipSetDevice(device));
+    if (!c->ready) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
+        HIP_TRY(hipMalloc(&c->d_table, sizeof(uint32_t) * (1 + ptau::SCALAR_TABLE_ENTRIES) * 24));
+        HIP_TRY(hipMalloc(&c->d_err, sizeof(int)));
+        c->ready = true;
+    }
+    return PTAU_OK;
+}
+
+int grow(void *&p, size_t &cap, size_t need, const Err &err) {
+    if (need <= cap) return PTAU_OK;
+    if (p) HIP_TRY(hipFree(p));
+    p = nullptr;
+    cap = 0;
+    HIP_TRY(hipMalloc(&p, need));
+    cap = need;
+    return PTAU_OK;
+}
+
+int errbits_to_code(int bits, const Err &err) {
+    if (!bits) return PTAU_OK;
+    if (bits & ptau::ERRBIT_NONCANONICAL) return err.fail(PTAU_E_POINT, "non-canonical field element in input");
+    if (bits & ptau::ERRBIT_NOT_ON_CURVE) return err.fail(PTAU_E_POINT, "compressed x coordinate is not on the curve");
+    if (bits & ptau::ERRBIT_INFINITY) return err.fail(PTAU_E_POINT_AT_INFINITY, "point at infinity where a non-zero element is required");
+    return err.fail(PTAU_E_NOT_IN_SUBGROUP, "element is not in the prime-order subgroup");
+}
+
+// One vector on device-resident buffers; caller holds the device mutex and has set the device.
+int run_apply_powers_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, int cin, uint8_t *d_out, int cout,
+                         uint64_t n, uint64_t start, const uint64_t *tau, const uint64_t *coeff, int check_input,
+                         const Err &err) {
+    const int isz = cin ? ops->comp : ops->uncomp, osz = cout ? ops->comp : ops->uncomp;
+    std::vector<uint32_t> table((1 + ptau::SCALAR_TABLE_ENTRIES) * ops->fr_limbs32);
+    for (uint64_t off = 0; off < n; off += MAX_LAUNCH_POINTS) {
+        const uint64_t m = std::min(MAX_LAUNCH_POINTS, n - off);
+        int rc;
+        if ((rc = grow(c->scratch, c->scratch_cap, m * ops->jac_bytes, err))) return rc;
+        if ((rc = grow(c->pre, c->pre_cap, m * ops->fe_bytes, err))) return rc;
+        ops->build_table(tau, coeff, start + off, table.data());
+        HIP_TRY(hipMemcpyAsync(c->d_table, table.data(), table.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
+        HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+        ops->scalar_mul(c->stream, d_in + off * isz, cin, c->scratch, m, c->d_table, check_input, c->d_err);
+        HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+        const uint64_t T = (m + NORMALIZE_GROUP - 1) / NORMALIZE_GROUP;
+        ops->normalize(c->stream, c->scratch, c->pre, d_out + off * osz, cout, m, T, 0, c->d_err);
+        HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+        int bits = 0;
+        HIP_TRY(hipMemcpyAsync(&bits, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipGetLastError());
+        float a = 0, b = 0;
+        HIP_TRY(hipEventElapsedTime(&a, c->ev[0], c->ev[1]));
+        HIP_TRY(hipEventElapsedTime(&b, c->ev[1], c->ev[2]));
+        c->timing.scalar_mul_ms += a;
+        c->timing.normalize_ms += b;
+        c->timing.kernel_ms += a + b;
+        c->timing.points += m;
+        if ((rc = errbits_to_code(bits, err))) return rc;
+    }
+    return PTAU_OK;
+}
+
+int run_apply_powers_host(DeviceCtx *c, const GroupOps *ops, const uint8_t *in, int cin, uint8_t *out, int cout, uint64_t n,
+                          uint64_t start, const uint64_t *tau, const uint64_t *coeff, int check_input, const Err &err) {
+    const size_t isz = cin ? ops->comp : ops->uncomp, osz = cout ? ops->comp : ops->uncomp;
+    if (!n) return PTAU_OK;
+    int rc;
+    if ((rc = grow(c->d_in, c->in_cap, n * isz, err))) return rc;
+    if ((rc = grow(c->d_out, c->out_cap, n * osz, err))) return rc;
+    float ms = 0;
+    HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_in, in, n * isz, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipEventRecord(c->ev[4], c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
+    c->timing.h2d_ms += ms;
+    if ((rc = run_apply_powers_dev(c, ops, (const uint8_t *)c->d_in, cin, (uint8_t *)c->d_out, cout, n, start, tau, coeff,
+                                   check_input, err)))
+        return rc;
+    HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+    HIP_TRY(hipMemcpyAsync(out, c->d_out, n * osz, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipEventRecord(c->ev[4], c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
+    c->timing.d2h_ms += ms;
+    return PTAU_OK;
+}
+
+int check_params(const ptau_params *p, const Err &err) {
+    if (!p) return err.fail(PTAU_E_ARG, "null parameters");
+    if (p->curve < 0 || p->curve > 3) return err.fail(PTAU_E_ARG, "unknown curve id %d", p->curve);
+    if (p->proving_system != PTAU_PROVING_GROTH16)
+        return err.fail(PTAU_E_UNSUPPORTED, "only the groth16 accumulator geometry is implemented");
+    if (p->contribution_mode != PTAU_MODE_CHUNKED && p->contribution_mode != PTAU_MODE_FULL)
+        return err.fail(PTAU_E_ARG, "unknown contribution mode %d", p->contribution_mode);
+    if (p->power > 40) return err.fail(PTAU_E_ARG, "power %u too large", p->power);
+    if (p->contribution_mode == PTAU_MODE_CHUNKED && p->chunk_size == 0) return err.fail(PTAU_E_ARG, "chunk_size is zero");
+    return PTAU_OK;
+}
+
+// ---- BLAKE2b-512 (RFC 7693), host CPU -------------------------------------------------------
+struct Blake2b {
+    uint64_t h[8], t0 = 0, t1 = 0;
+    uint8_t buf[128];
+    size_t fill = 0;
+    static constexpr uint64_t IV[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL,
+                                       0xa54ff53a5f1d36f1ULL, 0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL,
+                                       0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
+    Blake2b() {
+        for (int i = 0; i < 8; i++) h[i] = IV[i];
+        h[0] ^= 0x01010040ULL;   // digest 64 bytes, no key, fanout = depth = 1
+    }
+    static uint64_t rotr(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
+    void compress(const uint8_t *blk, bool last) {
+        static const uint8_t S[10][16] = {
+            {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+            {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+            {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+            {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+            {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0}};
+        uint64_t m[16], v[16];
+        memcpy(m, blk, 128);
+        for (int i = 0; i < 8; i++) { v[i] = h[i]; v[i + 8] = IV[i]; }
+        v[12] ^= t0;
+        v[13] ^= t1;
+        if (last) v[14] = ~v[14];
+        auto G = [&](int a, int b, int c, int d, uint64_t x, uint64_t y) {
+            v[a] += v[b] + x; v[d] = rotr(v[d] ^ v[a], 32);
+            v[c] += v[d];     v[b] = rotr(v[b] ^ v[c], 24);
+            v[a] += v[b] + y; v[d] = rotr(v[d] ^ v[a], 16);
+            v[c] += v[d];     v[b] = rotr(v[b] ^ v[c], 63);
+        };
+        for (int r = 0; r < 12; r++) {
+            const uint8_t *s = S[r % 10];
+            G(0, 4, 8, 12, m[s[0]], m[s[1]]);   G(1, 5, 9, 13, m[s[2]], m[s[3]]);
+            G(2, 6, 10, 14, m[s[4]], m[s[5]]);  G(3, 7, 11, 15, m[s[6]], m[s[7]]);
+            G(0, 5, 10, 15, m[s[8]], m[s[9]]);  G(1, 6, 11, 12, m[s[10]], m[s[11]]);
+            G(2, 7, 8, 13, m[s[12]], m[s[13]]); G(3, 4, 9, 14, m[s[14]], m[s[15]]);
+        }
+        for (int i = 0; i < 8; i++) h[i] ^= v[i] ^ v[i + 8];
+    }
+    void add_count(uint64_t n) {
+        t0 += n;
+        if (t0 < n) t1++;
+    }
+    void update(const uint8_t *p, size_t n) {
+        while (n) {
+            if (fill == 128) {   // buffer full and more data follows: not the last block
+                add_count(128);
+                compress(buf, false);
+                fill = 0;
+            }
+            size_t k = std::min(n, (size_t)128 - fill);
+            memcpy(buf + fill, p, k);
+            fill += k;
+            p += k;
+            n -= k;
+        }
+    }
+    void finish(uint8_t out[64]) {
+        add_count(fill);
+        memset(buf + fill, 0, 128 - fill);
+        compress(buf, true);
+        memcpy(out, h, 64);
+    }
+};
+constexpr uint64_t Blake2b::IV[8];
+
+struct MappedFile {
+    void *p = MAP_FAILED;
+    size_t len = 0;
+    int fd = -1;
+    ~MappedFile() {
+        if (p != MAP_FAILED) munmap(p, len);
+        if (fd >= 0) close(fd);
+    }
+    int open_ro(const char *path, const Err &err) {
+        fd = open(path, O_RDONLY);
+        if (fd < 0) return err.fail(PTAU_E_IO, "cannot open %s: %s", path, strerror(errno));
+        struct stat st;
+        if (fstat(fd, &st)) return err.fail(PTAU_E_IO, "cannot stat %s: %s", path, strerror(errno));
+        len = (size_t)st.st_size;
+        if (len) {
+            p = mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (p == MAP_FAILED) return err.fail(PTAU_E_IO, "cannot mmap %s: %s", path, strerror(errno));
+        }
+        return PTAU_OK;
+    }
+    int create_new(const char *path, size_t size, const Err &err) {
+        fd = open(path, O_RDWR | O_CREAT | O_EXCL, 0644);   // create_new semantics (contribute.rs:791-792)
+        if (fd < 0) return err.fail(PTAU_E_IO, "cannot create %s: %s", path, strerror(errno));
+        if (ftruncate(fd, (off_t)size)) return err.fail(PTAU_E_IO, "cannot size %s: %s", path, strerror(errno));
+        len = size;
+        p = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        if (p == MAP_FAILED) return err.fail(PTAU_E_IO, "cannot mmap %s: %s", path, strerror(errno));
+        return PTAU_OK;
+    }
+};
+
+int write_small_file(const char *path, const uint8_t *data, size_t n, const Err &err) {
+    FILE *f = fopen(path, "wb");
+    if (!f) return err.fail(PTAU_E_IO, "cannot create %s: %s", path, strerror(errno));
+    size_t w = fwrite(data, 1, n, f);
+    if (fclose(f) || w != n) return err.fail(PTAU_E_IO, "short write to %s", path);
+    return PTAU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *ptau_strerror(int code) {
+    switch (code) {
+    case PTAU_OK: return "ok";
+    case PTAU_E_ARG: return "invalid argument";
+    case PTAU_E_LEN: return "buffer length does not match the parameters";
+    case PTAU_E_POINT: return "invalid group element encoding";
+    case PTAU_E_POINT_AT_INFINITY: return "point at infinity";
+    case PTAU_E_NOT_IN_SUBGROUP: return "element not in the prime-order subgroup";
+    case PTAU_E_INVALID_RATIO: return "same-ratio check failed";
+    case PTAU_E_HASH_CHAIN: return "hash chain mismatch";
+    case PTAU_E_DEVICE: return "GPU device error";
+    case PTAU_E_IO: return "file I/O error";
+    case PTAU_E_UNSUPPORTED: return "unsupported configuration";
+    }
+    return "unknown error";
+}
+
+int ptau_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int ptau_device_info(int device, char *name, size_t name_len, int *compute_units, uint64_t *hbm_bytes) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return PTAU_E_DEVICE;
+    if (name && name_len) snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+    return PTAU_OK;
+}
+
+int ptau_point_size(int curve, int group, int compressed) {
+    const GroupOps *o = get_ops(curve, group);
+    if (!o) return PTAU_E_ARG;
+    return compressed ? o->comp : o->uncomp;
+}
+
+int ptau_fr_limbs(int curve) {
+    const GroupOps *o = get_ops(curve, 1);
+    return o ? (o->fr_limbs32 + 1) / 2 : PTAU_E_ARG;
+}
+
+int ptau_params_sizes(const ptau_params *p, ptau_sizes *out) {
+    Err err{nullptr, 0};
+    int rc = check_params(p, err);
+    if (rc) return rc;
+    if (!out) return PTAU_E_ARG;
+    const GroupOps *g1 = get_ops(p->curve, 1), *g2 = get_ops(p->curve, 2);
+    const uint64_t L = 1ull << p->power, G1L = 2 * L - 1;
+    const bool full = p->contribution_mode == PTAU_MODE_FULL;
+    const uint64_t start = full ? 0 : p->chunk_index * p->chunk_size;
+    auto clampc = [&](uint64_t total) -> uint64_t {
+        if (full) return total;
+        if (start >= total) return 0;
+        return std::min(p->chunk_size, total - start);
+    };
+    out->powers_length = L;
+    out->powers_g1_length = G1L;
+    out->g1_chunk_size = clampc(G1L);
+    out->other_chunk_size = clampc(L);
+    out->hash_size = 64;
+    out->start = start;
+    const uint64_t n1 = out->g1_chunk_size, n2 = out->other_chunk_size;
+    out->public_key_size = 6ull * g1->uncomp + 3ull * g2->uncomp;
+    out->accumulator_size = 64 + n1 * g1->uncomp + n2 * (g2->uncomp + 2ull * g1->uncomp) + g2->uncomp;
+    out->contribution_size = 64 + n1 * g1->comp + n2 * (g2->comp + 2ull * g1->comp) + g2->comp + out->public_key_size;
+    return PTAU_OK;
+}
+
+void ptau_blake2b512(const uint8_t *data, size_t len, uint8_t out[64]) {
+    Blake2b b;
+    b.update(data, len);
+    b.finish(out);
+}
+
+int ptau_last_timing(int device, ptau_timing *out) {
+    if (device < 0 || device >= MAX_DEVICES || !out) return PTAU_E_ARG;
+    std::lock_guard<std::mutex> lk(g_ctx[device].mu);
+    *out = g_ctx[device].timing;
+    return PTAU_OK;
+}
+
+int ptau_apply_powers_dev(int curve, int group, const void *d_in, int compressed_in, void *d_out, int compressed_out,
+                          uint64_t n, uint64_t start, const uint64_t *tau, const uint64_t *coeff, int check_input,
+                          int device, char *errbuf, size_t err_len) {
+    Err err{errbuf, err_len};
+    const GroupOps *ops = get_ops(curve, group);
+    if (!ops) return err.fail(PTAU_E_ARG, "unknown curve/group %d/%d", curve, group);
+    if (!tau || (n && (!d_in || !d_out))) return err.fail(PTAU_E_ARG, "null pointer argument");
+    DeviceCtx *c;
+    int rc = ensure_ctx(device, c, err);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(hipSetDevice(device));
+    c->timing = ptau_timing{};
+    return run_apply_powers_dev(c, ops, (const uint8_t *)d_in, compressed_in, (uint8_t *)d_out, compressed_out, n, start, tau,
+                                coeff, check_input, err);
+}
+
+int ptau_apply_powers(int curve, int group, const uint8_t *in, int compressed_in, uint8_t *out, int compressed_out, uint64_t n,
+                      uint64_t start, const uint64_t *tau, const uint64_t *coeff, int check_input, int device, char *errbuf,
+                      size_t err_len) {
+    Err err{errbuf, err_len};
+    const GroupOps *ops = get_ops(curve, group);
+    if (!ops) return err.fail(PTAU_E_ARG, "unknown curve/group %d/%d", curve, group);
+    if (!tau || (n && (!in || !out))) return err.fail(PTAU_E_ARG, "null pointer argument");
+    DeviceCtx *c;
+    int rc = ensure_ctx(device, c, err);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(hipSetDevice(device));
+    c->timing = ptau_timing{};
+    return run_apply_powers_host(c, ops, in, compressed_in, out, compressed_out, n, start, tau, coeff, check_input, err);
+}
+
+int ptau_phase1_computation(const ptau_params *p, const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len,
+                            const uint64_t *tau, const uint64_t *alpha, const uint64_t *beta, int check_input, int device,
+                            char *errbuf, size_t err_len) {
+    Err err{errbuf, err_len};
+    int rc = check_params(p, err);
+    if (rc) return rc;
+    if (!in || !out || !tau || !alpha || !beta) return err.fail(PTAU_E_ARG, "null pointer argument");
+    ptau_sizes sz;
+    ptau_params_sizes(p, &sz);
+    if (in_len != sz.accumulator_size)
+        return err.fail(PTAU_E_LEN, "challenge is %zu bytes, parameters require %llu", in_len,
+                        (unsigned long long)sz.accumulator_size);
+    if (out_len != sz.contribution_size)
+        return err.fail(PTAU_E_LEN, "response buffer is %zu bytes, parameters require %llu", out_len,
+                        (unsigned long long)sz.contribution_size);
+    const GroupOps *g1 = get_ops(p->curve, 1), *g2 = get_ops(p->curve, 2);
+    DeviceCtx *c;
+    if ((rc = ensure_ctx(device, c, err))) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(hipSetDevice(device));
+    c->timing = ptau_timing{};
+    const uint64_t n1 = sz.g1_chunk_size, n2 = sz.other_chunk_size, s = sz.start;
+    const uint8_t *pi = in + 64;
+    uint8_t *po = out + 64;
+    // tauG1 | tauG2 | alphaG1 | betaG1 | betaG2  (SURVEY App. A.1); exponent index is global: start + i
+    if ((rc = run_apply_powers_host(c, g1, pi, 0, po, 1, n1, s, tau, nullptr, check_input, err))) return rc;
+    pi += n1 * g1->uncomp; po += n1 * g1->comp;
+    if ((rc = run_apply_powers_host(c, g2, pi, 0, po, 1, n2, s, tau, nullptr, check_input, err))) return rc;
+    pi += n2 * g2->uncomp; po += n2 * g2->comp;
+    if ((rc = run_apply_powers_host(c, g1, pi, 0, po, 1, n2, s, tau, alpha, check_input, err))) return rc;
+    pi += n2 * g1->uncomp; po += n2 * g1->comp;
+    if ((rc = run_apply_powers_host(c, g1, pi, 0, po, 1, n2, s, tau, beta, check_input, err))) return rc;
+    pi += n2 * g1->uncomp; po += n2 * g1->comp;
+    // betaG2 <- beta * betaG2 : tau^0 with coefficient beta
+    return run_apply_powers_host(c, g2, pi, 0, po, 1, 1, 0, tau, beta, check_input, err);
+}
+
+int ptau_contribute_file(const ptau_params *p, const char *challenge_path, const char *challenge_hash_path,
+                         const char *response_path, const char *response_hash_path, const uint64_t *tau,
+                         const uint64_t *alpha, const uint64_t *beta, const uint8_t *public_key, size_t public_key_len,
+                         int check_input, int batch_exp_mode, int device, char *errbuf, size_t err_len) {
+    (void)batch_exp_mode;   // every BatchExpMode value selects the same GPU path
+    Err err{errbuf, err_len};
+    int rc = check_params(p, err);
+    if (rc) return rc;
+    if (!challenge_path || !challenge_hash_path || !response_path || !response_hash_path || !public_key)
+        return err.fail(PTAU_E_ARG, "null pointer argument");
+    ptau_sizes sz;
+    ptau_params_sizes(p, &sz);
+    if (public_key_len != sz.public_key_size)
+        return err.fail(PTAU_E_LEN, "public key is %zu bytes, expected %llu", public_key_len,
+                        (unsigned long long)sz.public_key_size);
+    MappedFile ch, resp;
+    if ((rc = ch.open_ro(challenge_path, err))) return rc;
+    if (ch.len != sz.accumulator_size)
+        return err.fail(PTAU_E_LEN, "challenge file is %zu bytes, parameters require %llu", ch.len,
+                        (unsigned long long)sz.accumulator_size);
+    uint8_t digest[64];
+    ptau_blake2b512((const uint8_t *)ch.p, ch.len, digest);
+    if ((rc = write_small_file(challenge_hash_path, digest, 64, err))) return rc;
+    if ((rc = resp.create_new(response_path, sz.contribution_size, err))) return rc;
+    uint8_t *out = (uint8_t *)resp.p;
+    memcpy(out, digest, 64);
+    if ((rc = ptau_phase1_computation(p, (const uint8_t *)ch.p, ch.len, out, resp.len, tau, alpha, beta, check_input, device,
+                                      errbuf, err_len)))
+        return rc;
+    memcpy(out + sz.contribution_size - sz.public_key_size, public_key, public_key_len);
+    ptau_blake2b512(out, resp.len, digest);
+    if (msync(resp.p, resp.len, MS_SYNC)) return err.fail(PTAU_E_IO, "msync failed: %s", strerror(errno));
+    return write_small_file(response_hash_path, digest, 64, err);
+}
+
+int ptau_decompress(int curve, int group, const uint8_t *in, uint8_t *out, uint64_t n, int check_output, int device,
+                    char *errbuf, size_t err_len) {
+    Err err{errbuf, err_len};
+    const GroupOps *ops = get_ops(curve, group);
+    if (!ops) return err.fail(PTAU_E_ARG, "unknown curve/group %d/%d", curve, group);
+    if (n && (!in || !out)) return err.fail(PTAU_E_ARG, "null pointer argument");
+    DeviceCtx *c;
+    int rc = ensure_ctx(device, c, err);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(hipSetDevice(device));
+    c->timing = ptau_timing{};
+    if (!n) return PTAU_OK;
+    if ((rc = grow(c->d_in, c->in_cap, n * ops->comp, err))) return rc;
+    if ((rc = grow(c->d_out, c->out_cap, n * ops->uncomp, err))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_in, in, n * ops->comp, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
+    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    ops->decompress(c->stream, (const uint8_t *)c->d_in, (uint8_t *)c->d_out, n, (check_output & 1), c->d_err);
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    int bits = 0;
+    HIP_TRY(hipMemcpyAsync(&bits, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(out, c->d_out, n * ops->uncomp, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    c->timing.kernel_ms = ms;
+    c->timing.points = n;
+    return errbits_to_code(bits, err);
+}
+
+}  // extern "C"

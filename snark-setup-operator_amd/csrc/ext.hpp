@@ -1,0 +1,198 @@
+// Quadratic / cubic extension fields Fq[u]/(u^D - NR) over a Montgomery base field.
+//
+// MI355X-native equivalent of ark-ff 0.4.2 QuadExtField / CubicExtField (the G2 base fields of
+// BLS12-377, MNT4-753 (D = 2) and MNT6-753 (D = 3)); NR is a small signed integer so the
+// non-residue product is a short addition chain instead of a field multiplication.
+#pragma once
+#include "fp.hpp"
+
+namespace ptau {
+
+template <class F, int NR>
+struct Fp2 {
+    static constexpr int DEG = 2;
+    static constexpr int BYTES = 2 * F::BYTES;
+    using Base = F;
+    F c0, c1;
+
+    PTAU_HD static Fp2 zero() { return {F::zero(), F::zero()}; }
+    PTAU_HD static Fp2 one() { return {F::one(), F::zero()}; }
+    PTAU_HD bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
+    PTAU_HD bool operator==(const Fp2 &b) const { return c0 == b.c0 && c1 == b.c1; }
+    PTAU_HD bool operator!=(const Fp2 &b) const { return !(*this == b); }
+    PTAU_HD static Fp2 add(const Fp2 &a, const Fp2 &b) { return {F::add(a.c0, b.c0), F::add(a.c1, b.c1)}; }
+    PTAU_HD static Fp2 sub(const Fp2 &a, const Fp2 &b) { return {F::sub(a.c0, b.c0), F::sub(a.c1, b.c1)}; }
+    PTAU_HD static Fp2 neg(const Fp2 &a) { return {F::neg(a.c0), F::neg(a.c1)}; }
+    PTAU_HD static Fp2 dbl(const Fp2 &a) { return {F::dbl(a.c0), F::dbl(a.c1)}; }
+    static constexpr bool MUL_OUT_OF_LINE = true;
+    __host__ __device__ __noinline__ static Fp2 mul_out(const Fp2 &a, const Fp2 &b) { return mul_inl(a, b); }
+    __host__ __device__ __noinline__ static Fp2 sqr_out(const Fp2 &a) { return sqr_inl(a); }
+    PTAU_HD static Fp2 mul(const Fp2 &a, const Fp2 &b) {
+        if constexpr (MUL_OUT_OF_LINE) return mul_out(a, b);
+        else return mul_inl(a, b);
+    }
+    PTAU_HD static Fp2 sqr(const Fp2 &a) {
+        if constexpr (MUL_OUT_OF_LINE) return sqr_out(a);
+        else return sqr_inl(a);
+    }
+    // Karatsuba: 3 base multiplications
+    PTAU_HD static Fp2 mul_inl(const Fp2 &a, const Fp2 &b) {
+        F v0 = F::mul(a.c0, b.c0);
+        F v1 = F::mul(a.c1, b.c1);
+        F s = F::mul(F::add(a.c0, a.c1), F::add(b.c0, b.c1));
+        Fp2 r;
+        r.c1 = F::sub(F::sub(s, v0), v1);
+        r.c0 = F::add(v0, F::mul_small(v1, NR));
+        return r;
+    }
+    // complex squaring: 2 base multiplications
+    PTAU_HD static Fp2 sqr_inl(const Fp2 &a) {
+        F v0 = F::mul(a.c0, a.c1);
+        F t = F::mul(F::add(a.c0, a.c1), F::add(a.c0, F::mul_small(a.c1, NR)));
+        Fp2 r;
+        r.c0 = F::sub(F::sub(t, v0), F::mul_small(v0, NR));
+        r.c1 = F::dbl(v0);
+        return r;
+    }
+    PTAU_HD static Fp2 mul_base(const Fp2 &a, const F &k) { return {F::mul(a.c0, k), F::mul(a.c1, k)}; }
+    __host__ __device__ __noinline__ static Fp2 inverse(const Fp2 &a) {
+        F n = F::sub(F::sqr(a.c0), F::mul_small(F::sqr(a.c1), NR));
+        F ni = F::inverse(n);
+        return {F::mul(a.c0, ni), F::neg(F::mul(a.c1, ni))};
+    }
+    // sqrt via the norm (complex method): 2 base sqrts + 1 inversion
+    __host__ __device__ __noinline__ static bool sqrt(const Fp2 &a, Fp2 &out) {
+        if (a.c1.is_zero()) {
+            F r;
+            if (F::sqrt(a.c0, r)) { out = {r, F::zero()}; return true; }
+            // a0 = NR * y^2  =>  sqrt = y*u
+            F t = F::mul(a.c0, F::inverse(F::mul_small(F::one(), NR)));
+            if (!F::sqrt(t, r)) return false;
+            out = {F::zero(), r};
+            return true;
+        }
+        F norm = F::sub(F::sqr(a.c0), F::mul_small(F::sqr(a.c1), NR));
+        F alpha;
+        if (!F::sqrt(norm, alpha)) return false;
+        // two_inv = 1/2
+        F two_inv = F::inverse(F::dbl(F::one()));
+        F delta = F::mul(F::add(a.c0, alpha), two_inv);
+        F x0;
+        if (!F::sqrt(delta, x0)) {
+            delta = F::mul(F::sub(a.c0, alpha), two_inv);
+            if (!F::sqrt(delta, x0)) return false;
+        }
+        if (x0.is_zero()) return false;
+        F x1 = F::mul(F::mul(a.c1, two_inv), F::inverse(x0));
+        out = {x0, x1};
+        return sqr(out) == a;
+    }
+    PTAU_HD static bool read_bytes(const uint8_t *in, bool with_flags, uint8_t *flags, Fp2 &out) {
+        uint8_t dummy = 0;
+        bool ok = F::read_bytes(in, false, &dummy, out.c0);
+        ok &= F::read_bytes(in + F::BYTES, with_flags, flags, out.c1);
+        return ok;
+    }
+    PTAU_HD void write_bytes(uint8_t *out, uint8_t flags) const {
+        c0.write_bytes(out, 0);
+        c1.write_bytes(out + F::BYTES, flags);
+    }
+    // arkworks Ord: highest coefficient first
+    PTAU_HD int sign_class() const {
+        int s = c1.sign_class();
+        return s ? s : c0.sign_class();
+    }
+};
+
+template <class F, int NR>
+struct Fp3 {
+    static constexpr int DEG = 3;
+    static constexpr int BYTES = 3 * F::BYTES;
+    using Base = F;
+    F c0, c1, c2;
+
+    PTAU_HD static Fp3 zero() { return {F::zero(), F::zero(), F::zero()}; }
+    PTAU_HD static Fp3 one() { return {F::one(), F::zero(), F::zero()}; }
+    PTAU_HD bool is_zero() const { return c0.is_zero() && c1.is_zero() && c2.is_zero(); }
+    PTAU_HD bool operator==(const Fp3 &b) const { return c0 == b.c0 && c1 == b.c1 && c2 == b.c2; }
+    PTAU_HD bool operator!=(const Fp3 &b) const { return !(*this == b); }
+    PTAU_HD static Fp3 add(const Fp3 &a, const Fp3 &b) { return {F::add(a.c0, b.c0), F::add(a.c1, b.c1), F::add(a.c2, b.c2)}; }
+    PTAU_HD static Fp3 sub(const Fp3 &a, const Fp3 &b) { return {F::sub(a.c0, b.c0), F::sub(a.c1, b.c1), F::sub(a.c2, b.c2)}; }
+    PTAU_HD static Fp3 neg(const Fp3 &a) { return {F::neg(a.c0), F::neg(a.c1), F::neg(a.c2)}; }
+    PTAU_HD static Fp3 dbl(const Fp3 &a) { return {F::dbl(a.c0), F::dbl(a.c1), F::dbl(a.c2)}; }
+    static constexpr bool MUL_OUT_OF_LINE = true;
+    __host__ __device__ __noinline__ static Fp3 mul_out(const Fp3 &a, const Fp3 &b) { return mul_inl(a, b); }
+    PTAU_HD static Fp3 mul(const Fp3 &a, const Fp3 &b) {
+        if constexpr (MUL_OUT_OF_LINE) return mul_out(a, b);
+        else return mul_inl(a, b);
+    }
+    // Karatsuba-style: 6 base multiplications
+    PTAU_HD static Fp3 mul_inl(const Fp3 &a, const Fp3 &b) {
+        F v0 = F::mul(a.c0, b.c0), v1 = F::mul(a.c1, b.c1), v2 = F::mul(a.c2, b.c2);
+        F t12 = F::sub(F::sub(F::mul(F::add(a.c1, a.c2), F::add(b.c1, b.c2)), v1), v2);   // a1b2 + a2b1
+        F t01 = F::sub(F::sub(F::mul(F::add(a.c0, a.c1), F::add(b.c0, b.c1)), v0), v1);   // a0b1 + a1b0
+        F t02 = F::sub(F::sub(F::mul(F::add(a.c0, a.c2), F::add(b.c0, b.c2)), v0), v2);   // a0b2 + a2b0
+        Fp3 r;
+        r.c0 = F::add(v0, F::mul_small(t12, NR));
+        r.c1 = F::add(t01, F::mul_small(v2, NR));
+        r.c2 = F::add(t02, v1);
+        return r;
+    }
+    PTAU_HD static Fp3 sqr(const Fp3 &a) { return mul(a, a); }
+    __host__ __device__ __noinline__ static Fp3 inverse(const Fp3 &a) {
+        F t0 = F::sub(F::sqr(a.c0), F::mul_small(F::mul(a.c1, a.c2), NR));
+        F t1 = F::sub(F::mul_small(F::sqr(a.c2), NR), F::mul(a.c0, a.c1));
+        F t2 = F::sub(F::sqr(a.c1), F::mul(a.c0, a.c2));
+        F n = F::add(F::mul(a.c0, t0), F::mul_small(F::add(F::mul(a.c2, t1), F::mul(a.c1, t2)), NR));
+        F ni = F::inverse(n);
+        return {F::mul(t0, ni), F::mul(t1, ni), F::mul(t2, ni)};
+    }
+    // Frobenius a -> a^q
+    PTAU_HD static Fp3 frobenius(const Fp3 &a) {
+        F c1, c2;
+#pragma unroll
+        for (int i = 0; i < F::N; i++) { c1.l[i] = F::Params::FROB3_C1[i]; c2.l[i] = F::Params::FROB3_C2[i]; }
+        return {a.c0, F::mul(a.c1, c1), F::mul(a.c2, c2)};
+    }
+    __host__ __device__ __noinline__ static Fp3 pow_limbs(const Fp3 &a, const uint32_t *e, int top_bit) {
+        Fp3 r = one();
+        for (int i = top_bit; i >= 0; i--) {
+            r = sqr(r);
+            if ((e[i >> 5] >> (i & 31)) & 1u) r = mul(r, a);
+        }
+        return r;
+    }
+    // sqrt through the norm: b = (a^((q+1)/2))^q = a^((q^2+q)/2), so b^2 * a = a^(1+q+q^2) = N(a) in Fq
+    // and sqrt(a) = sqrt_Fq(N(a)) / b.   One 753-bit Fq3 exponentiation + one base-field sqrt.
+    __host__ __device__ __noinline__ static bool sqrt(const Fp3 &a, Fp3 &out) {
+        if (a.is_zero()) { out = zero(); return true; }
+        Fp3 b = frobenius(pow_limbs(a, F::Params::QP1H, F::Params::BITS - 1));
+        Fp3 nrm = mul(sqr(b), a);
+        if (!nrm.c1.is_zero() || !nrm.c2.is_zero()) return false;   // cannot happen for valid field data
+        F s;
+        if (!F::sqrt(nrm.c0, s)) return false;
+        Fp3 bi = inverse(b);
+        out = {F::mul(bi.c0, s), F::mul(bi.c1, s), F::mul(bi.c2, s)};
+        return sqr(out) == a;
+    }
+    PTAU_HD static bool read_bytes(const uint8_t *in, bool with_flags, uint8_t *flags, Fp3 &out) {
+        uint8_t dummy = 0;
+        bool ok = F::read_bytes(in, false, &dummy, out.c0);
+        ok &= F::read_bytes(in + F::BYTES, false, &dummy, out.c1);
+        ok &= F::read_bytes(in + 2 * F::BYTES, with_flags, flags, out.c2);
+        return ok;
+    }
+    PTAU_HD void write_bytes(uint8_t *out, uint8_t flags) const {
+        c0.write_bytes(out, 0);
+        c1.write_bytes(out + F::BYTES, 0);
+        c2.write_bytes(out + 2 * F::BYTES, flags);
+    }
+    PTAU_HD int sign_class() const {
+        int s = c2.sign_class();
+        if (s) return s;
+        s = c1.sign_class();
+        return s ? s : c0.sign_class();
+    }
+};
+
+}  // namespace ptau

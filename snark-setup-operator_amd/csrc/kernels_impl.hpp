@@ -1,0 +1,327 @@
+// HIP kernels of the chunk tau-update (K1) and point decompression (K2), templated over one
+// group of one curve; each curve's translation unit instantiates them (k_<curve>.hip).
+//
+// Replaces setup-utils' apply_powers / batch_exp / read_batch / write_batch and
+// Phase1::decompress — reference call sites /root/reference/src/bin/contribute.rs:811-823, 968-986.
+//
+// Pipeline per vector of n points (all device-resident):
+//   scalar_mul_kernel : thread i derives e_i = c * tau^(start+i) from a tau^(2^k) table, reads
+//                       point i (uncompressed, or compressed + sqrt), runs the scalar multiplication
+//                       and stores the Jacobian result to scratch.
+//   normalize_kernel  : Montgomery-trick batched inversion (one inversion per K points), affine
+//                       conversion, arkworks serialisation (sign flag from the canonical y).
+#pragma once
+#include "ec.hpp"
+
+namespace ptau {
+
+// Error bits accumulated in a device word by the kernels.
+enum : int { ERRBIT_NONCANONICAL = 1, ERRBIT_NOT_ON_CURVE = 2, ERRBIT_INFINITY = 4, ERRBIT_NOT_IN_SUBGROUP = 8 };
+
+constexpr int SCALAR_TABLE_ENTRIES = 64;   // tau^(2^k), k < 64, preceded by the base coefficient
+
+// Host+device view of one group's types.
+template <class FqP, class FrP, class Cfg>
+struct GroupTypes {
+    using Fq = Fp<FqP>;
+    using Fr = Fp<FrP>;
+    using F = std::conditional_t<Cfg::DEG == 1, Fq,
+              std::conditional_t<Cfg::DEG == 2, Fp2<Fq, Cfg::NR>, Fp3<Fq, Cfg::NR>>>;
+    using J = Jac<F, Cfg>;
+    using A = Affine<F>;
+    static constexpr int COMP = F::BYTES;
+    static constexpr int UNCOMP = 2 * F::BYTES;
+};
+
+// table layout: [0] = base coefficient c*tau^start, [1+k] = tau^(2^k); all Montgomery, Fr::N limbs
+template <class Fr>
+PTAU_HD Fr scalar_for_index(const uint32_t *__restrict__ table, uint64_t idx) {
+    Fr e;
+#pragma unroll
+    for (int i = 0; i < Fr::N; i++) e.l[i] = table[i];
+    for (int k = 0; idx != 0; k++, idx >>= 1) {
+        if (idx & 1) {
+            Fr t;
+#pragma unroll
+            for (int i = 0; i < Fr::N; i++) t.l[i] = table[(1 + k) * Fr::N + i];
+            e = Fr::mul(e, t);
+        }
+    }
+    return e;
+}
+
+// MSB-first double-and-add with mixed additions (ark-ec sw_double_and_add_affine).
+template <class G, int NL>
+PTAU_HD typename G::J scalar_mul_bits(const typename G::A &p, const uint32_t (&k)[NL], int top_bit) {
+    using J = typename G::J;
+    J acc = J::infinity();
+    for (int i = top_bit; i >= 0; i--) {
+        acc = J::dbl(acc);
+        uint32_t w = 0;
+#pragma unroll
+        for (int j = 0; j < NL; j++) w = (j == (i >> 5)) ? k[j] : w;   // register select, no scratch
+        if ((w >> (i & 31)) & 1u) acc = J::add_mixed(acc, p);
+    }
+    return acc;
+}
+
+// Per-thread bodies are host+device so tests/native/host_emul.hip can run the SAME code on the
+// CPU (test infrastructure only; the product has no CPU path).  Each returns its error bits.
+template <class G>
+PTAU_HD int read_point_any(const uint8_t *in, int compressed_in, uint64_t i, typename G::A &p) {
+    using J = typename G::J;
+    int bad = 0;
+    if (compressed_in) {
+        int rc = read_compressed<typename G::F, typename J::CfgT>(in + i * G::COMP, p);
+        if (rc == 1) bad |= ERRBIT_NONCANONICAL;
+        if (rc == 2) bad |= ERRBIT_NOT_ON_CURVE;
+    } else {
+        if (!read_uncompressed<typename G::F>(in + i * G::UNCOMP, p)) bad |= ERRBIT_NONCANONICAL;
+    }
+    return bad;
+}
+
+template <class G>
+PTAU_HD int scalar_mul_thread(const uint8_t *in, int compressed_in, typename G::J *scratch, uint64_t i,
+                              const uint32_t *table, int check_input) {
+    using Fr = typename G::Fr;
+    using A = typename G::A;
+    using J = typename G::J;
+    A p;
+    int bad = read_point_any<G>(in, compressed_in, i, p);
+    if ((check_input & 1) && p.inf) bad |= ERRBIT_INFINITY;
+    if (bad) {
+        scratch[i] = J::infinity();
+        return bad;
+    }
+    Fr e = scalar_for_index<Fr>(table, i);
+    uint32_t k[Fr::N];
+    e.to_canonical(k);
+    scratch[i] = scalar_mul_bits<G, Fr::N>(p, k, Fr::Params::BITS - 1);
+    return 0;
+}
+
+template <class G>
+__global__ void __launch_bounds__(256)
+scalar_mul_kernel(const uint8_t *__restrict__ in, int compressed_in, typename G::J *__restrict__ scratch,
+                  uint64_t n, const uint32_t *__restrict__ table, int check_input, int *__restrict__ err) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int bad = scalar_mul_thread<G>(in, compressed_in, scratch, i, table, check_input);
+    if (bad) atomicOr(err, bad);
+}
+
+// Scalar multiplication of every point by ONE public scalar of `nbits` bits (subgroup check with
+// the group order, cofactor clearing): result Jacobian to scratch.
+template <class G>
+PTAU_HD int fixed_scalar_mul_thread(const uint8_t *in, int compressed_in, typename G::J *scratch, uint64_t i,
+                                    const uint32_t *scalar, int nbits) {
+    using A = typename G::A;
+    using J = typename G::J;
+    A p;
+    int bad = read_point_any<G>(in, compressed_in, i, p);
+    if (bad) {
+        scratch[i] = J::infinity();
+        return bad;
+    }
+    J acc = J::infinity();
+    for (int b = nbits - 1; b >= 0; b--) {
+        acc = J::dbl(acc);
+        if ((scalar[b >> 5] >> (b & 31)) & 1u) acc = J::add_mixed(acc, p);   // wave-uniform branch
+    }
+    scratch[i] = acc;
+    return 0;
+}
+
+template <class G>
+__global__ void __launch_bounds__(256)
+fixed_scalar_mul_kernel(const uint8_t *__restrict__ in, int compressed_in, typename G::J *__restrict__ scratch,
+                        uint64_t n, const uint32_t *__restrict__ scalar, int nbits, int *__restrict__ err) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int bad = fixed_scalar_mul_thread<G>(in, compressed_in, scratch, i, scalar, nbits);
+    if (bad) atomicOr(err, bad);
+}
+
+// Batched normalisation + serialisation.  Thread t owns elements t, t+T, t+2T, ... (< n).
+template <class G>
+PTAU_HD int normalize_thread(const typename G::J *scratch, typename G::F *pre, uint8_t *out, int compressed_out,
+                             uint64_t n, uint64_t T, uint64_t t, int check_nonzero) {
+    using F = typename G::F;
+    using A = typename G::A;
+    int bad = 0;
+    F acc = F::one();
+    for (uint64_t i = t; i < n; i += T) {
+        pre[i] = acc;
+        F z = scratch[i].Z;
+        if (!z.is_zero()) acc = F::mul(acc, z);
+    }
+    F inv = F::inverse(acc);
+    uint64_t cnt = (n - t + T - 1) / T;
+    const int osz = compressed_out ? G::COMP : G::UNCOMP;
+    for (uint64_t j = cnt; j-- > 0;) {
+        uint64_t i = t + j * T;
+        typename G::J q = scratch[i];
+        A a;
+        if (q.Z.is_zero()) {
+            a.inf = true;
+            a.x = F::zero();
+            a.y = F::zero();
+            if (check_nonzero) bad |= ERRBIT_INFINITY;
+        } else {
+            F zi = F::mul(inv, pre[i]);
+            inv = F::mul(inv, q.Z);
+            F zi2 = F::sqr(zi);
+            a.x = F::mul(q.X, zi2);
+            a.y = F::mul(q.Y, F::mul(zi2, zi));
+            a.inf = false;
+        }
+        write_point<F>(out + i * osz, a, compressed_out != 0);
+    }
+    return bad;
+}
+
+template <class G>
+__global__ void __launch_bounds__(256)
+normalize_kernel(const typename G::J *__restrict__ scratch, typename G::F *__restrict__ pre,
+                 uint8_t *__restrict__ out, int compressed_out, uint64_t n, uint64_t T,
+                 int check_nonzero, int *__restrict__ err) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    int bad = normalize_thread<G>(scratch, pre, out, compressed_out, n, T, t, check_nonzero);
+    if (bad) atomicOr(err, bad);
+}
+
+// Flag every scratch point that is NOT the point at infinity (subgroup check: r*P must be O).
+template <class G>
+__global__ void __launch_bounds__(256)
+expect_infinity_kernel(const typename G::J *__restrict__ scratch, uint64_t n, int *__restrict__ err) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (!scratch[i].Z.is_zero()) atomicOr(err, ERRBIT_NOT_IN_SUBGROUP);
+}
+
+// K2: compressed -> uncompressed (Phase1::decompress); no scalar multiplication.
+template <class G>
+PTAU_HD int decompress_thread(const uint8_t *in, uint8_t *out, uint64_t i, int check_nonzero) {
+    using A = typename G::A;
+    using J = typename G::J;
+    A p;
+    int rc = read_compressed<typename G::F, typename J::CfgT>(in + i * G::COMP, p);
+    int bad = 0;
+    if (rc == 1) bad |= ERRBIT_NONCANONICAL;
+    if (rc == 2) bad |= ERRBIT_NOT_ON_CURVE;
+    if (check_nonzero && p.inf) bad |= ERRBIT_INFINITY;
+    if (rc) { p.inf = true; p.x = G::F::zero(); p.y = G::F::zero(); }
+    write_point<typename G::F>(out + i * G::UNCOMP, p, false);
+    return bad;
+}
+
+template <class G>
+__global__ void __launch_bounds__(256)
+decompress_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, uint64_t n, int check_nonzero,
+                  int *__restrict__ err) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int bad = decompress_thread<G>(in, out, i, check_nonzero);
+    if (bad) atomicOr(err, bad);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host-side launchers, one table per (curve, group); capi.hip dispatches through these.
+struct GroupOps {
+    int comp, uncomp;          // serialized sizes
+    size_t jac_bytes, fe_bytes;
+    int fr_limbs32, fr_bits;
+    // builds the device scalar table on the host: [base, tau^(2^k)...] Montgomery 32-bit limbs
+    void (*build_table)(const uint64_t *tau, const uint64_t *coeff, uint64_t start, uint32_t *out);
+    void (*scalar_mul)(hipStream_t, const uint8_t *in, int cin, void *scratch, uint64_t n, const uint32_t *table,
+                       int check_input, int *err);
+    void (*fixed_scalar_mul)(hipStream_t, const uint8_t *in, int cin, void *scratch, uint64_t n,
+                             const uint32_t *scalar, int nbits, int *err);
+    void (*normalize)(hipStream_t, const void *scratch, void *pre, uint8_t *out, int cout, uint64_t n, uint64_t T,
+                      int check_nonzero, int *err);
+    void (*expect_infinity)(hipStream_t, const void *scratch, uint64_t n, int *err);
+    void (*decompress)(hipStream_t, const uint8_t *in, uint8_t *out, uint64_t n, int check_nonzero, int *err);
+    const uint32_t *group_order;   // r, canonical 32-bit limbs (fr_limbs32)
+};
+
+template <class G>
+struct Launch {
+    using Fr = typename G::Fr;
+    static dim3 grid(uint64_t n) { return dim3((unsigned)((n + 255) / 256)); }
+
+    static void build_table(const uint64_t *tau, const uint64_t *coeff, uint64_t start, uint32_t *out) {
+        constexpr int N = Fr::N;
+        uint32_t c[N];
+        auto load = [&](const uint64_t *src) {
+            for (int i = 0; i < N; i++) c[i] = (uint32_t)(src[i / 2] >> (32 * (i & 1)));
+            return Fr::from_canonical(c);
+        };
+        Fr t = load(tau);
+        Fr base = coeff ? load(coeff) : Fr::one();
+        // base *= tau^start
+        Fr pw = t;
+        for (uint64_t s = start; s; s >>= 1) {
+            if (s & 1) base = Fr::mul(base, pw);
+            pw = Fr::sqr(pw);
+        }
+        for (int i = 0; i < N; i++) out[i] = base.l[i];
+        pw = t;
+        for (int k = 0; k < SCALAR_TABLE_ENTRIES; k++) {
+            for (int i = 0; i < N; i++) out[(1 + k) * N + i] = pw.l[i];
+            pw = Fr::sqr(pw);
+        }
+    }
+    static void scalar_mul(hipStream_t s, const uint8_t *in, int cin, void *scratch, uint64_t n, const uint32_t *table,
+                           int check_input, int *err) {
+        if (!n) return;
+        hipLaunchKernelGGL(scalar_mul_kernel<G>, grid(n), dim3(256), 0, s, in, cin, (typename G::J *)scratch, n, table,
+                           check_input, err);
+    }
+    static void fixed_scalar_mul(hipStream_t s, const uint8_t *in, int cin, void *scratch, uint64_t n,
+                                 const uint32_t *scalar, int nbits, int *err) {
+        if (!n) return;
+        hipLaunchKernelGGL(fixed_scalar_mul_kernel<G>, grid(n), dim3(256), 0, s, in, cin, (typename G::J *)scratch, n,
+                           scalar, nbits, err);
+    }
+    static void normalize(hipStream_t s, const void *scratch, void *pre, uint8_t *out, int cout, uint64_t n, uint64_t T,
+                          int check_nonzero, int *err) {
+        if (!n) return;
+        hipLaunchKernelGGL(normalize_kernel<G>, grid(T), dim3(256), 0, s, (const typename G::J *)scratch,
+                           (typename G::F *)pre, out, cout, n, T, check_nonzero, err);
+    }
+    static void expect_infinity(hipStream_t s, const void *scratch, uint64_t n, int *err) {
+        if (!n) return;
+        hipLaunchKernelGGL(expect_infinity_kernel<G>, grid(n), dim3(256), 0, s, (const typename G::J *)scratch, n, err);
+    }
+    static void decompress(hipStream_t s, const uint8_t *in, uint8_t *out, uint64_t n, int check_nonzero, int *err) {
+        if (!n) return;
+        hipLaunchKernelGGL(decompress_kernel<G>, grid(n), dim3(256), 0, s, in, out, n, check_nonzero, err);
+    }
+    static GroupOps ops() {
+        GroupOps o;
+        o.comp = G::COMP;
+        o.uncomp = G::UNCOMP;
+        o.jac_bytes = sizeof(typename G::J);
+        o.fe_bytes = sizeof(typename G::F);
+        o.fr_limbs32 = Fr::N;
+        o.fr_bits = Fr::Params::BITS;
+        o.build_table = build_table;
+        o.scalar_mul = scalar_mul;
+        o.fixed_scalar_mul = fixed_scalar_mul;
+        o.normalize = normalize;
+        o.expect_infinity = expect_infinity;
+        o.decompress = decompress;
+        o.group_order = Fr::Params::MOD;
+        return o;
+    }
+};
+
+// one accessor per curve TU
+const GroupOps *ops_bls12_377(int group);
+const GroupOps *ops_bw6_761(int group);
+const GroupOps *ops_mnt4_753(int group);
+const GroupOps *ops_mnt6_753(int group);
+
+}  // namespace ptau

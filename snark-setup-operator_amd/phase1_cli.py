@@ -1,0 +1,209 @@
+"""Host-side mirror of the phase1-cli / phase1 / setup-utils surface the operator uses.
+
+Same names, argument meaning and error behaviour as the reference's L1 calls — where the Rust
+functions panic, these raise PtauError:
+  * Phase1Parameters::{new_chunk,new_full}          /root/reference/src/utils.rs:326-352
+  * phase1_cli::contribute                          /root/reference/src/bin/contribute.rs:811-823
+  * batch_exp_mode_from_str / subgroup_check_mode_from_str   contribute.rs:134-145
+  * CheckForCorrectness / UseCompression            contribute.rs:38-43
+  * calculate_hash                                  /root/reference/src/bin/verify_transcript.rs:344-345
+All arithmetic runs in libptau_hip.so (HIP, gfx950) through the C ABI; nothing here computes.
+The private key is an INPUT (`rng` in the reference): key generation stays on the Rust host.
+"""
+import ctypes
+import enum
+import os
+from dataclasses import dataclass
+
+from . import _lib
+
+CURVE_KINDS = {"bls12_377": 0, "bw6": 1, "mnt4_753": 2, "mnt6_753": 3}
+
+
+class ContributionMode(enum.IntEnum):
+    Chunked = 0
+    Full = 1
+
+
+class ProvingSystem(enum.IntEnum):
+    Groth16 = 0
+    Marlin = 1
+
+
+class CheckForCorrectness(enum.IntEnum):
+    No = 0
+    OnlyNonZero = 1
+    OnlyInGroup = 2
+    Full = 3
+
+
+class UseCompression(enum.IntEnum):
+    No = 0
+    Yes = 1
+
+
+class BatchExpMode(enum.IntEnum):
+    Auto = 0
+    Direct = 1
+    BatchInversion = 2
+
+
+class SubgroupCheckMode(enum.IntEnum):
+    Auto = 0
+    Direct = 1
+    Batched = 2
+    No = 3
+
+
+def batch_exp_mode_from_str(s: str) -> BatchExpMode:
+    try:
+        return {"auto": BatchExpMode.Auto, "direct": BatchExpMode.Direct, "batch-inversion": BatchExpMode.BatchInversion}[s]
+    except KeyError:
+        raise ValueError("unknown batch exp mode %r" % s)
+
+
+def subgroup_check_mode_from_str(s: str) -> SubgroupCheckMode:
+    try:
+        return {"auto": SubgroupCheckMode.Auto, "direct": SubgroupCheckMode.Direct, "batched": SubgroupCheckMode.Batched,
+                "no": SubgroupCheckMode.No}[s]
+    except KeyError:
+        raise ValueError("unknown subgroup check mode %r" % s)
+
+
+def proving_system_from_str(s: str) -> ProvingSystem:
+    try:
+        return {"groth16": ProvingSystem.Groth16, "marlin": ProvingSystem.Marlin}[s]
+    except KeyError:
+        raise ValueError("unknown proving system %r" % s)
+
+
+def curve_from_str(s: str) -> int:
+    """curve_kind dispatch (contribute.rs:1156-1211)."""
+    try:
+        return CURVE_KINDS[s]
+    except KeyError:
+        raise ValueError("unknown curve kind %r" % s)
+
+
+def upgrade_correctness_check_config(default: CheckForCorrectness, force: bool) -> CheckForCorrectness:
+    """contribute.rs:816-819: --force-correctness-checks upgrades every check to Full."""
+    return CheckForCorrectness.Full if force else default
+
+
+@dataclass(frozen=True)
+class Phase1Parameters:
+    curve: int
+    contribution_mode: ContributionMode
+    chunk_index: int
+    chunk_size: int
+    proving_system: ProvingSystem
+    total_size_in_log2: int
+    batch_size: int
+
+    @staticmethod
+    def new_chunk(curve_kind, contribution_mode, chunk_index, chunk_size, proving_system, power, batch_size):
+        c = curve_from_str(curve_kind) if isinstance(curve_kind, str) else int(curve_kind)
+        return Phase1Parameters(c, ContributionMode(contribution_mode), chunk_index, chunk_size,
+                                ProvingSystem(proving_system), power, batch_size)
+
+    @staticmethod
+    def new_full(curve_kind, proving_system, power, batch_size):
+        c = curve_from_str(curve_kind) if isinstance(curve_kind, str) else int(curve_kind)
+        return Phase1Parameters(c, ContributionMode.Full, 0, 1 << power, ProvingSystem(proving_system), power, batch_size)
+
+    def _c(self):
+        return _lib.ptau_params(self.curve, int(self.proving_system), int(self.contribution_mode), self.total_size_in_log2,
+                                self.chunk_index, self.chunk_size, self.batch_size)
+
+    def _sizes(self):
+        s = _lib.ptau_sizes()
+        rc = _lib.load_library().ptau_params_sizes(ctypes.byref(self._c()), ctypes.byref(s))
+        if rc:
+            raise _lib.PtauError(rc, "invalid parameters")
+        return s
+
+    # fields of Phase1Parameters the reference reads (new_setup.rs:274-277, utils.rs:526-532)
+    powers_length = property(lambda self: self._sizes().powers_length)
+    powers_g1_length = property(lambda self: self._sizes().powers_g1_length)
+    g1_chunk_size = property(lambda self: self._sizes().g1_chunk_size)
+    other_chunk_size = property(lambda self: self._sizes().other_chunk_size)
+    accumulator_size = property(lambda self: self._sizes().accumulator_size)
+    contribution_size = property(lambda self: self._sizes().contribution_size)
+    public_key_size = property(lambda self: self._sizes().public_key_size)
+    hash_size = property(lambda self: self._sizes().hash_size)
+
+
+@dataclass(frozen=True)
+class PrivateKey:
+    """phase1::PrivateKey{tau, alpha, beta} as canonical integers + the serialized PublicKey
+    (uncompressed, 6 G1 + 3 G2) produced by the host's Phase1::key_generation."""
+    tau: int
+    alpha: int
+    beta: int
+    public_key: bytes
+
+
+def calculate_hash(data: bytes) -> bytes:
+    out = ctypes.create_string_buffer(64)
+    _lib.load_library().ptau_blake2b512(data, len(data), out)
+    return out.raw
+
+
+def contribute(challenge_filename, challenge_hash_filename, response_filename, response_hash_filename,
+               check_input_correctness, batch_exp_mode, parameters: Phase1Parameters, key: PrivateKey, device: int = 0):
+    """phase1_cli::contribute (contribute.rs:811-823); `key` replaces `rng`."""
+    L = _lib.load_library()
+    nl = L.ptau_fr_limbs(parameters.curve)
+    eb = _lib.errbuf()
+    rc = L.ptau_contribute_file(ctypes.byref(parameters._c()), os.fsencode(challenge_filename),
+                                os.fsencode(challenge_hash_filename), os.fsencode(response_filename),
+                                os.fsencode(response_hash_filename), _lib.limbs(key.tau, nl), _lib.limbs(key.alpha, nl),
+                                _lib.limbs(key.beta, nl), key.public_key, len(key.public_key),
+                                int(check_input_correctness), int(batch_exp_mode), device, eb, len(eb))
+    _lib.check(rc, eb)
+
+
+def computation(challenge: bytes, parameters: Phase1Parameters, key: PrivateKey, check_input=CheckForCorrectness.No,
+                device: int = 0) -> bytes:
+    """Phase1::computation on in-memory buffers: returns a contribution_size buffer whose element
+    region is filled (hash header and public-key tail left zero)."""
+    L = _lib.load_library()
+    nl = L.ptau_fr_limbs(parameters.curve)
+    out = ctypes.create_string_buffer(parameters.contribution_size)
+    eb = _lib.errbuf()
+    rc = L.ptau_phase1_computation(ctypes.byref(parameters._c()), challenge, len(challenge), out, len(out),
+                                   _lib.limbs(key.tau, nl), _lib.limbs(key.alpha, nl), _lib.limbs(key.beta, nl),
+                                   int(check_input), device, eb, len(eb))
+    _lib.check(rc, eb)
+    return out.raw
+
+
+def apply_powers(curve, group, data: bytes, n, start, tau, coeff=None, compressed_in=False, compressed_out=True,
+                 check_input=CheckForCorrectness.No, device=0) -> bytes:
+    """setup-utils apply_powers / batch_exp on one vector (host buffers)."""
+    L = _lib.load_library()
+    c = curve_from_str(curve) if isinstance(curve, str) else int(curve)
+    nl = L.ptau_fr_limbs(c)
+    out = ctypes.create_string_buffer(max(1, n * L.ptau_point_size(c, group, int(compressed_out))))
+    eb = _lib.errbuf()
+    rc = L.ptau_apply_powers(c, group, data, int(compressed_in), out, int(compressed_out), n, start, _lib.limbs(tau, nl),
+                             None if coeff is None else _lib.limbs(coeff, nl), int(check_input), device, eb, len(eb))
+    _lib.check(rc, eb)
+    return out.raw[:n * L.ptau_point_size(c, group, int(compressed_out))]
+
+
+def decompress(curve, group, data: bytes, n, check_output=CheckForCorrectness.No, device=0) -> bytes:
+    """Phase1::decompress on one vector (host buffers)."""
+    L = _lib.load_library()
+    c = curve_from_str(curve) if isinstance(curve, str) else int(curve)
+    out = ctypes.create_string_buffer(max(1, n * L.ptau_point_size(c, group, 0)))
+    eb = _lib.errbuf()
+    rc = L.ptau_decompress(c, group, data, out, n, int(check_output), device, eb, len(eb))
+    _lib.check(rc, eb)
+    return out.raw[:n * L.ptau_point_size(c, group, 0)]
+
+
+def last_timing(device=0):
+    t = _lib.ptau_timing()
+    _lib.load_library().ptau_last_timing(device, ctypes.byref(t))
+    return {k: getattr(t, k) for k, _ in _lib.ptau_timing._fields_}

@@ -1,0 +1,51 @@
+import importlib.util
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CURVE_NAMES = ["bls12_377", "bw6", "mnt4_753", "mnt6_753"]
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def load_package():
+    """Import the hyphenated package directory under the name snark_setup_operator_amd."""
+    if "snark_setup_operator_amd" in sys.modules:
+        return sys.modules["snark_setup_operator_amd"]
+    p = os.path.join(ROOT, "snark-setup-operator_amd", "__init__.py")
+    spec = importlib.util.spec_from_file_location("snark_setup_operator_amd", p,
+                                                  submodule_search_locations=[os.path.dirname(p)])
+    m = importlib.util.module_from_spec(spec)
+    sys.modules["snark_setup_operator_amd"] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    return load_package()
+
+
+@pytest.fixture(scope="session")
+def cref():
+    from oracle import cref as c
+    c.lib()
+    return c
+
+
+def load_golden(curve):
+    with open(os.path.join(ROOT, "tests", "golden", "phase1_%s.json" % curve)) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return {c: load_golden(c) for c in CURVE_NAMES}

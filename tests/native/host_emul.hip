@@ -1,0 +1,73 @@
+// TEST INFRASTRUCTURE: runs the kernels' per-thread bodies (kernels_impl.hpp, host+device code) on
+// the CPU so the field / curve / serde templates can be checked against the oracle without a GPU.
+// Not part of the product: libptau_hip.so has no CPU path.
+//
+// usage: host_emul <op> <curve> <group> <n> <start> <cin> <cout> <tau_hex> <coeff_hex|-> < in > out
+//   op = apply | decompress
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels_impl.hpp"
+
+using namespace ptau;
+
+static std::vector<uint64_t> parse_hex(const char *h, int limbs) {
+    std::vector<uint64_t> v(limbs, 0);
+    size_t len = strlen(h);
+    for (size_t i = 0; i < len; i++) {
+        char ch = h[len - 1 - i];
+        uint64_t d = ch <= '9' ? ch - '0' : (ch | 32) - 'a' + 10;
+        if (i / 16 < (size_t)limbs) v[i / 16] |= d << (4 * (i % 16));
+    }
+    return v;
+}
+
+template <class G>
+static int run(const std::string &op, uint64_t n, uint64_t start, int cin, int cout, const char *tau_hex,
+               const char *coeff_hex) {
+    const size_t isz = cin ? G::COMP : G::UNCOMP, osz = cout ? G::COMP : G::UNCOMP;
+    std::vector<uint8_t> in(n * isz), out;
+    if (fread(in.data(), 1, in.size(), stdin) != in.size()) return 2;
+    int bad = 0;
+    if (op == "decompress") {
+        out.resize(n * G::UNCOMP);
+        for (uint64_t i = 0; i < n; i++) bad |= decompress_thread<G>(in.data(), out.data(), i, 0);
+    } else {
+        out.resize(n * osz);
+        const int fl = (G::Fr::N + 1) / 2;
+        auto tau = parse_hex(tau_hex, fl);
+        std::vector<uint64_t> coeff;
+        if (strcmp(coeff_hex, "-")) coeff = parse_hex(coeff_hex, fl);
+        std::vector<uint32_t> table((1 + SCALAR_TABLE_ENTRIES) * G::Fr::N);
+        Launch<G>::build_table(tau.data(), coeff.empty() ? nullptr : coeff.data(), start, table.data());
+        std::vector<typename G::J> scratch(n);
+        std::vector<typename G::F> pre(n);
+        for (uint64_t i = 0; i < n; i++) bad |= scalar_mul_thread<G>(in.data(), cin, scratch.data(), i, table.data(), 0);
+        uint64_t T = (n + 3) / 4;
+        for (uint64_t t = 0; t < T; t++) bad |= normalize_thread<G>(scratch.data(), pre.data(), out.data(), cout, n, T, t, 0);
+    }
+    fwrite(out.data(), 1, out.size(), stdout);
+    return bad ? 3 : 0;
+}
+
+#define DISPATCH(FQ, FR, C1, C2)                                                                  \
+    if (group == 1) return run<GroupTypes<FQ, FR, C1>>(op, n, start, cin, cout, argv[8], argv[9]); \
+    return run<GroupTypes<FQ, FR, C2>>(op, n, start, cin, cout, argv[8], argv[9]);
+
+int main(int argc, char **argv) {
+    if (argc < 10) return 1;
+    std::string op = argv[1];
+    int curve = atoi(argv[2]), group = atoi(argv[3]);
+    uint64_t n = strtoull(argv[4], 0, 10), start = strtoull(argv[5], 0, 10);
+    int cin = atoi(argv[6]), cout = atoi(argv[7]);
+    switch (curve) {
+    case 0: DISPATCH(BlsFq, BlsFr, BlsG1Cfg, BlsG2Cfg)
+    case 1: DISPATCH(Bw6Fq, Bw6Fr, Bw6G1Cfg, Bw6G2Cfg)
+    case 2: DISPATCH(Mnt4Fq, Mnt4Fr, Mnt4G1Cfg, Mnt4G2Cfg)
+    case 3: DISPATCH(Mnt6Fq, Mnt6Fr, Mnt6G1Cfg, Mnt6G2Cfg)
+    }
+    return 1;
+}

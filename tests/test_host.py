@@ -1,0 +1,101 @@
+"""CPU tests of the host logic and of the C-ABI library surface (no compute calls: no GPU here)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import CURVE_NAMES, ROOT
+from oracle.pyref import phase1 as P
+from oracle.pyref.curves import CURVES
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    L = pkg.load_library()
+    header = open(os.path.join(ROOT, "include", "ptau.h")).read()
+    declared = set(re.findall(r"\b(ptau_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(pkg._lib.DECLARED_SYMBOLS)
+    for s in declared:
+        assert hasattr(L, s), s
+
+
+def test_params_sizes_match_oracle(pkg):
+    for name in CURVE_NAMES:
+        for (mode, idx, cs, pw) in ((0, 0, 4, 2), (0, 1, 4, 2), (0, 0, 1 << 10, 12), (0, 5, 1 << 10, 12), (0, 7, 1 << 10, 12),
+                                    (0, 0, 1 << 20, 20), (0, 1, 1 << 20, 20), (0, 3, 1 << 18, 20), (0, 4, 1 << 18, 20), (1, 0, 1 << 20, 20)):
+            q = P.Params(CURVES[name], mode, idx, cs, pw, cs)
+            h = pkg.Phase1Parameters.new_chunk(name, mode, idx, cs, 0, pw, cs)
+            assert (h.g1_chunk_size, h.other_chunk_size, h.accumulator_size, h.contribution_size, h.public_key_size,
+                    h.hash_size) == (q.g1_chunk_size, q.other_chunk_size, q.accumulator_size, q.contribution_size,
+                                     q.public_key_size, 64)
+            assert h.powers_length == 1 << pw and h.powers_g1_length == (2 << pw) - 1
+    # number of chunks as new_setup computes it (new_setup.rs:274-277)
+    h = pkg.Phase1Parameters.new_chunk("bw6", 0, 0, 1 << 18, 0, 20, 1 << 18)
+    assert -(-h.powers_g1_length // (1 << 18)) == 8
+
+
+def test_host_blake2b(pkg, cref):
+    import hashlib
+    for n in (0, 1, 127, 128, 129, 256, 100003):
+        d = bytes((i * 7 + 3) & 0xFF for i in range(n))
+        assert pkg.calculate_hash(d) == hashlib.blake2b(d).digest() == cref.blake2b512(d)
+
+
+def test_mode_parsers_and_errors(pkg):
+    assert pkg.batch_exp_mode_from_str("auto") == pkg.BatchExpMode.Auto
+    assert pkg.subgroup_check_mode_from_str("batched") == pkg.SubgroupCheckMode.Batched
+    assert pkg.proving_system_from_str("groth16") == pkg.ProvingSystem.Groth16
+    with pytest.raises(ValueError):
+        pkg.curve_from_str("bn254")
+    with pytest.raises(pkg.PtauError):   # Marlin geometry is not implemented: loud, not silent
+        pkg.Phase1Parameters.new_chunk("bw6", 0, 0, 4, 1, 2, 4).accumulator_size
+
+
+def test_no_cpu_fallback_without_gpu(pkg):
+    """On a box without a GPU every compute entry point must fail with PTAU_E_DEVICE."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(pkg.PtauError) as e:
+        pkg.phase1_cli.apply_powers("bls12_377", 1, bytes(96), 1, 0, 5)
+    assert e.value.code == -8
+
+
+def test_product_never_links_the_oracle(pkg):
+    out = subprocess.run(["ldd", pkg._lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "ptau_oracle" not in out
+    for root, _, files in os.walk(os.path.join(ROOT, "snark-setup-operator_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".inc")):
+                txt = open(os.path.join(root, f)).read()
+                assert "oracle/" not in txt.replace("test oracle", "") or f == "gen_constants.py", f
+                assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+@pytest.mark.parametrize("name", CURVE_NAMES)
+def test_kernel_bodies_on_host_match_golden(name, golden):
+    """tests/native/host_emul runs the kernels' per-thread bodies (same templates) on the CPU."""
+    exe = os.path.join(ROOT, "tests", "native", "host_emul")
+    if not os.path.exists(exe):
+        pytest.skip("host_emul not built (python -c 'import __graft_entry__ as g; g.build()')")
+    doc = golden[name]
+    c = CURVES[name]
+    cid = CURVE_NAMES.index(name)
+    ch = doc["chunks"][0]
+    p = P.Params(c, P.CHUNKED, 0, doc["chunk_size"], doc["power"], doc["batch_size"])
+    challenge, response = bytes.fromhex(ch["challenge"]), bytes.fromhex(ch["response"])
+    lay_in, lay_out = p.layout(False)[0], p.layout(True)[0]
+    coeffs = {"tau_g1": "-", "tau_g2": "-", "alpha_g1": ch["alpha"], "beta_g1": ch["beta"]}
+    for (nm, grp, off, cnt), (_, _, ooff, _) in zip(lay_in, lay_out):
+        usz, csz = c.uncomp_size(grp), c.comp_size(grp)
+        if nm == "beta_g2":
+            args = ["apply", cid, grp, 1, 0, 0, 1, "1", ch["beta"]]
+        else:
+            args = ["apply", cid, grp, cnt, p.start, 0, 1, ch["tau"], coeffs[nm]]
+        r = subprocess.run([exe] + [str(a) for a in args], input=challenge[off:off + cnt * usz], capture_output=True)
+        assert r.returncode == 0
+        assert r.stdout == response[ooff:ooff + cnt * csz], nm
+        d = subprocess.run([exe, "decompress", str(cid), str(grp), str(cnt), "0", "1", "0", "0", "-"],
+                           input=response[ooff:ooff + cnt * csz], capture_output=True)
+        assert d.returncode == 0 and len(d.stdout) == cnt * usz
