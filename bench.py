@@ -39,10 +39,33 @@ def det_scalar(tag):
     return int.from_bytes(hashlib.blake2b(tag.encode(), digest_size=64).digest(), "little") % BLS_R
 
 
+def usable_cores():
+    """Threads this process may really use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return min(n, int(os.environ.get("PTAU_BENCH_CPU_THREADS", "64")))
+
+
+def pmc_traffic():
+    """HBM bytes per scalar_mul_kernel launch from the committed rocprofv3 PMC summary (profiles/)."""
+    try:
+        import glob
+        f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))[-1]
+        d = json.load(open(f))
+        return d["kernels"]["scalar_mul_kernel"]["hbm_bytes_per_launch"], os.path.basename(f)
+    except Exception:
+        return None, None
+
+
 def cpu_baseline(sample_points, chal_bytes, start, tau):
     """The C oracle ("port") timed on this host's cores over a bounded sample of the same workload."""
     from oracle import cref
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     cref.lib()
     t0 = time.time()
     out = cref.apply_powers("bls12_377", 1, chal_bytes, sample_points, start, tau, None, False, True, nthreads=cores)
@@ -58,7 +81,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log2-points", type=int, default=20)
-    ap.add_argument("--cpu-sample", type=int, default=32768)
+    ap.add_argument("--cpu-sample", type=int, default=65536)
     args = ap.parse_args()
 
     import torch
@@ -132,6 +155,7 @@ def main():
         got = d_resp[:sample * 48].cpu().numpy().tobytes()
         if got != ref:
             raise SystemExit("PARITY FAILURE: GPU response differs from the CPU oracle on the sampled points")
+        traffic, traffic_src = pmc_traffic()
         name = ctypes.create_string_buffer(128)
         L.ptau_device_info(dev, name, 128, None, None)
         print(json.dumps({
@@ -143,7 +167,7 @@ def main():
                                    "(2^%d points, uncompressed in -> compressed out, HBM-resident)" % args.log2_points,
                        "points_per_step_per_gpu": n, "device": name.value.decode(), "parity": "bit-exact vs CPU oracle on %d sampled points" % sample},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "scalar_mul_kernel<BLS12-377 G1>", "kernel_ms": smul_ms / args.steps,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "scalar_mul_kernel<BLS12-377 G1>", "kernel_ms": smul_ms / args.steps,
                          "normalize_kernel_ms": norm_ms / args.steps,
                          "note": "integer-ALU-bound by construction (~0.9 M 32-bit MACs per update vs 144 B): see DESIGN.md"},
             "cpu_baseline": base,
