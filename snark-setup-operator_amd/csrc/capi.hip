@@ -14,6 +14,7 @@
 #include <cerrno>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -60,14 +61,24 @@ const GroupOps *get_ops(int curve, int group) {
 constexpr int MAX_DEVICES = 16;
 constexpr uint64_t MAX_LAUNCH_POINTS = 1ull << 20;   // points per kernel launch (scratch sizing)
 constexpr uint64_t NORMALIZE_GROUP = 32;             // points per inversion in normalize_kernel
+constexpr uint64_t MAX_WINDOW_TABLE_BYTES = 6ull << 30;   // per-point window tables (8 Jacobian multiples each)
+
+// PTAU_SCALAR_MUL=bits selects the plain double-and-add kernel (A/B measurements); default: windowed.
+bool use_window_kernel() {
+    static const bool v = [] {
+        const char *e = getenv("PTAU_SCALAR_MUL");
+        return !(e && strcmp(e, "bits") == 0);
+    }();
+    return v;
+}
 
 struct DeviceCtx {
     std::mutex mu;
     bool ready = false;
     hipStream_t stream = nullptr;
     hipEvent_t ev[6] = {};
-    void *scratch = nullptr, *pre = nullptr;
-    size_t scratch_cap = 0, pre_cap = 0;
+    void *scratch = nullptr, *pre = nullptr, *wtab = nullptr;
+    size_t scratch_cap = 0, pre_cap = 0, wtab_cap = 0;
     uint32_t *d_table = nullptr;   // scalar table (65 entries x 24 limbs max)
     int *d_err = nullptr;
     void *d_in = nullptr, *d_out = nullptr;   // staging for the host-buffer entry points
@@ -118,16 +129,24 @@ int run_apply_powers_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in,
                          const Err &err) {
     const int isz = cin ? ops->comp : ops->uncomp, osz = cout ? ops->comp : ops->uncomp;
     std::vector<uint32_t> table((1 + ptau::SCALAR_TABLE_ENTRIES) * ops->fr_limbs32);
-    for (uint64_t off = 0; off < n; off += MAX_LAUNCH_POINTS) {
-        const uint64_t m = std::min(MAX_LAUNCH_POINTS, n - off);
+    const bool windowed = use_window_kernel();
+    const uint64_t launch_cap = windowed
+        ? std::max<uint64_t>(256, std::min(MAX_LAUNCH_POINTS, MAX_WINDOW_TABLE_BYTES / (ptau::WINDOW_ENTRIES * ops->jac_bytes)))
+        : MAX_LAUNCH_POINTS;
+    for (uint64_t off = 0; off < n; off += launch_cap) {
+        const uint64_t m = std::min(launch_cap, n - off);
         int rc;
         if ((rc = grow(c->scratch, c->scratch_cap, m * ops->jac_bytes, err))) return rc;
+        if (windowed && (rc = grow(c->wtab, c->wtab_cap, m * ptau::WINDOW_ENTRIES * ops->jac_bytes, err))) return rc;
         if ((rc = grow(c->pre, c->pre_cap, m * ops->fe_bytes, err))) return rc;
         ops->build_table(tau, coeff, start + off, table.data());
         HIP_TRY(hipMemcpyAsync(c->d_table, table.data(), table.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
         HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-        ops->scalar_mul(c->stream, d_in + off * isz, cin, c->scratch, m, c->d_table, check_input, c->d_err);
+        if (windowed)
+            ops->window_scalar_mul(c->stream, d_in + off * isz, cin, c->scratch, c->wtab, m, c->d_table, check_input, c->d_err);
+        else
+            ops->scalar_mul(c->stream, d_in + off * isz, cin, c->scratch, m, c->d_table, check_input, c->d_err);
         HIP_TRY(hipEventRecord(c->ev[1], c->stream));
         const uint64_t T = (m + NORMALIZE_GROUP - 1) / NORMALIZE_GROUP;
         ops->normalize(c->stream, c->scratch, c->pre, d_out + off * osz, cout, m, T, 0, c->d_err);

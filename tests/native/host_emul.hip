@@ -45,7 +45,13 @@ static int run(const std::string &op, uint64_t n, uint64_t start, int cin, int c
         Launch<G>::build_table(tau.data(), coeff.empty() ? nullptr : coeff.data(), start, table.data());
         std::vector<typename G::J> scratch(n);
         std::vector<typename G::F> pre(n);
-        for (uint64_t i = 0; i < n; i++) bad |= scalar_mul_thread<G>(in.data(), cin, scratch.data(), i, table.data(), 0);
+        if (getenv("PTAU_SCALAR_MUL") && !strcmp(getenv("PTAU_SCALAR_MUL"), "bits")) {
+            for (uint64_t i = 0; i < n; i++) bad |= scalar_mul_thread<G>(in.data(), cin, scratch.data(), i, table.data(), 0);
+        } else {
+            std::vector<typename G::J> wtab(n * WINDOW_ENTRIES);
+            for (uint64_t i = 0; i < n; i++)
+                bad |= window_scalar_mul_thread<G>(in.data(), cin, scratch.data(), wtab.data(), n, i, table.data(), 0);
+        }
         uint64_t T = (n + 3) / 4;
         for (uint64_t t = 0; t < T; t++) bad |= normalize_thread<G>(scratch.data(), pre.data(), out.data(), cout, n, T, t, 0);
     }
