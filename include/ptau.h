@@ -136,6 +136,31 @@ int ptau_contribute_file(const ptau_params *p, const char *challenge_path, const
 int ptau_decompress(int curve, int group, const uint8_t *in, uint8_t *out, uint64_t n, int check_output,
                     int device, char *err, size_t err_len);
 
+/* setup-utils check_subgroup (SubgroupCheckMode::Direct) + on-curve test for n HOST-resident points —
+ * CheckForCorrectness::OnlyInGroup of read_batch (src/bin/contribute.rs:971-980).
+ * Fails with PTAU_E_NOT_IN_SUBGROUP / PTAU_E_POINT. */
+int ptau_subgroup_check(int curve, int group, const uint8_t *in, int compressed_in, uint64_t n, int device,
+                        char *err, size_t err_len);
+
+/* Phase1::verification (element part) + Phase1::decompress — inside
+ * phase1_cli::transform_pok_and_correctness (src/bin/contribute.rs:968-986):
+ *   - response[0..64) must equal BLAKE2b(challenge)             -> PTAU_E_HASH_CHAIN
+ *   - every response element: canonical, on the curve, non-zero per check_output, in the prime-order
+ *     subgroup unless subgroup_check_mode == PTAU_SUBGROUP_NO      -> PTAU_E_POINT / _AT_INFINITY / _NOT_IN_SUBGROUP
+ *   - new_challenge = BLAKE2b(response) | decompressed elements (accumulator_size bytes).
+ * The proof-of-knowledge and ratio pairing checks are the O(1) tail (ptau_check_same_ratio). */
+int ptau_verify_chunk(const ptau_params *p, const uint8_t *challenge, size_t challenge_len, const uint8_t *response,
+                      size_t response_len, uint8_t *new_challenge, size_t new_challenge_len, int check_input,
+                      int check_output, int subgroup_check_mode, int ratio_check, int device, char *err, size_t err_len);
+
+/* phase1_cli::transform_pok_and_correctness, file level (src/bin/contribute.rs:968-986): writes the three
+ * 64-byte `.hash` side files and creates new_challenge_path (create_new semantics). */
+int ptau_transform_pok_and_correctness_file(const ptau_params *p, const char *challenge_path,
+                                            const char *challenge_hash_path, int check_input, const char *response_path,
+                                            const char *response_hash_path, int check_output,
+                                            const char *new_challenge_path, const char *new_challenge_hash_path,
+                                            int subgroup_check_mode, int ratio_check, int device, char *err, size_t err_len);
+
 /* Timings of the most recent compute call on `device`. */
 int ptau_last_timing(int device, ptau_timing *out);
 

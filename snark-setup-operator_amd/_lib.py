@@ -18,7 +18,8 @@ ERR_NAMES = {-1: "PTAU_E_ARG", -2: "PTAU_E_LEN", -3: "PTAU_E_POINT", -4: "PTAU_E
 DECLARED_SYMBOLS = [
     "ptau_strerror", "ptau_device_count", "ptau_device_info", "ptau_params_sizes", "ptau_point_size",
     "ptau_fr_limbs", "ptau_blake2b512", "ptau_apply_powers", "ptau_apply_powers_dev", "ptau_phase1_computation",
-    "ptau_contribute_file", "ptau_decompress", "ptau_last_timing",
+    "ptau_contribute_file", "ptau_decompress", "ptau_last_timing", "ptau_subgroup_check", "ptau_verify_chunk",
+    "ptau_transform_pok_and_correctness_file",
 ]
 
 
@@ -71,6 +72,9 @@ def load_library():
     L.ptau_contribute_file.argtypes = [ctypes.POINTER(ptau_params), cp, cp, cp, cp, u64p, u64p, u64p, u8p, sz, i, i, i, cp, sz]
     L.ptau_decompress.argtypes = [i, i, u8p, u8p, u64, i, i, cp, sz]
     L.ptau_last_timing.argtypes = [i, ctypes.POINTER(ptau_timing)]
+    L.ptau_subgroup_check.argtypes = [i, i, u8p, i, u64, i, cp, sz]
+    L.ptau_verify_chunk.argtypes = [ctypes.POINTER(ptau_params), u8p, sz, u8p, sz, u8p, sz, i, i, i, i, i, cp, sz]
+    L.ptau_transform_pok_and_correctness_file.argtypes = [ctypes.POINTER(ptau_params), cp, cp, i, cp, cp, i, cp, cp, i, i, i, cp, sz]
     _lib = L
     return L
 

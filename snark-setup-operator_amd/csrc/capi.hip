@@ -144,11 +144,13 @@ int run_apply_powers_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in,
         HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
         HIP_TRY(hipEventRecord(c->ev[0], c->stream));
         if (windowed)
-            ops->window_scalar_mul(c->stream, d_in + off * isz, cin, c->scratch, c->wtab, m, c->d_table, check_input, c->d_err);
+            ops->window_scalar_mul(c->stream, d_in + off * isz, cin, c->scratch, c->wtab, m, c->d_table, check_input, nullptr, c->d_err);
         else
             ops->scalar_mul(c->stream, d_in + off * isz, cin, c->scratch, m, c->d_table, check_input, c->d_err);
         HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-        const uint64_t T = (m + NORMALIZE_GROUP - 1) / NORMALIZE_GROUP;
+        // points per inversion: enough threads to fill the chip (>= 64 Ki) while amortising the inversion
+        const uint64_t grp = std::max<uint64_t>(4, std::min<uint64_t>(NORMALIZE_GROUP, m >> 16));
+        const uint64_t T = (m + grp - 1) / grp;
         ops->normalize(c->stream, c->scratch, c->pre, d_out + off * osz, cout, m, T, 0, c->d_err);
         HIP_TRY(hipEventRecord(c->ev[2], c->stream));
         int bits = 0;
@@ -186,6 +188,84 @@ int run_apply_powers_host(DeviceCtx *c, const GroupOps *ops, const uint8_t *in, 
         return rc;
     HIP_TRY(hipEventRecord(c->ev[3], c->stream));
     HIP_TRY(hipMemcpyAsync(out, c->d_out, n * osz, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipEventRecord(c->ev[4], c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
+    c->timing.d2h_ms += ms;
+    return PTAU_OK;
+}
+
+bool cofactor_is_one(int curve, int group) {
+    return group == PTAU_G1 && (curve == PTAU_CURVE_MNT4_753 || curve == PTAU_CURVE_MNT6_753);
+}
+
+// Prime-order-subgroup membership of n device-resident points (setup-utils check_subgroup, Direct mode):
+// on-curve test for uncompressed encodings, then [r]P == O with the windowed kernel and ONE public scalar.
+// Cofactor-1 groups (MNT G1) need only the on-curve test.  Caller holds the device mutex.
+int run_subgroup_check_dev(DeviceCtx *c, int curve, int group, const GroupOps *ops, const uint8_t *d_in, int cin, uint64_t n,
+                           const Err &err) {
+    if (!n) return PTAU_OK;
+    const int isz = cin ? ops->comp : ops->uncomp;
+    const uint64_t launch_cap =
+        std::max<uint64_t>(256, std::min(MAX_LAUNCH_POINTS, MAX_WINDOW_TABLE_BYTES / (ptau::WINDOW_ENTRIES * ops->jac_bytes)));
+    HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_table, ops->group_order, sizeof(uint32_t) * ops->fr_limbs32, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    if (!cin) ops->on_curve(c->stream, d_in, n, c->d_err);
+    if (!cofactor_is_one(curve, group)) {
+        for (uint64_t off = 0; off < n; off += launch_cap) {
+            const uint64_t m = std::min(launch_cap, n - off);
+            int rc;
+            if ((rc = grow(c->scratch, c->scratch_cap, m * ops->jac_bytes, err))) return rc;
+            if ((rc = grow(c->wtab, c->wtab_cap, m * ptau::WINDOW_ENTRIES * ops->jac_bytes, err))) return rc;
+            ops->window_scalar_mul(c->stream, d_in + off * isz, cin, c->scratch, c->wtab, m, c->d_table, 0, c->d_table, c->d_err);
+            ops->expect_infinity(c->stream, c->scratch, m, c->d_err);
+        }
+    }
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    int bits = 0;
+    HIP_TRY(hipMemcpyAsync(&bits, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    c->timing.kernel_ms += ms;
+    c->timing.scalar_mul_ms += ms;
+    c->timing.points += n;
+    return errbits_to_code(bits, err);
+}
+
+// One response vector of a chunk: compressed host bytes -> (sqrt) -> non-zero / subgroup checks -> uncompressed
+// host bytes of the next challenge.  Caller holds the device mutex.
+int run_verify_vector(DeviceCtx *c, int curve, int group, const GroupOps *ops, const uint8_t *in, uint8_t *out, uint64_t n,
+                      int check_output, int subgroup_check_mode, const Err &err) {
+    if (!n) return PTAU_OK;
+    int rc;
+    if ((rc = grow(c->d_in, c->in_cap, n * ops->comp, err))) return rc;
+    if ((rc = grow(c->d_out, c->out_cap, n * ops->uncomp, err))) return rc;
+    float ms = 0;
+    HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_in, in, n * ops->comp, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
+    HIP_TRY(hipEventRecord(c->ev[4], c->stream));
+    const int nonzero = (check_output == PTAU_CHECK_ONLY_NON_ZERO || check_output == PTAU_CHECK_FULL) ? 1 : 0;
+    ops->decompress(c->stream, (const uint8_t *)c->d_in, (uint8_t *)c->d_out, n, nonzero, c->d_err);
+    HIP_TRY(hipEventRecord(c->ev[5], c->stream));
+    int bits = 0;
+    HIP_TRY(hipMemcpyAsync(&bits, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
+    c->timing.h2d_ms += ms;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[4], c->ev[5]));
+    c->timing.kernel_ms += ms;
+    c->timing.normalize_ms += ms;   // decompress time is reported in this slot for the verify path
+    if ((rc = errbits_to_code(bits, err))) return rc;
+    const bool want_subgroup = subgroup_check_mode != PTAU_SUBGROUP_NO || check_output == PTAU_CHECK_ONLY_IN_GROUP ||
+                               check_output == PTAU_CHECK_FULL;
+    if (want_subgroup && (rc = run_subgroup_check_dev(c, curve, group, ops, (const uint8_t *)c->d_out, 0, n, err))) return rc;
+    HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+    HIP_TRY(hipMemcpyAsync(out, c->d_out, n * ops->uncomp, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipEventRecord(c->ev[4], c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
@@ -534,6 +614,100 @@ int ptau_decompress(int curve, int group, const uint8_t *in, uint8_t *out, uint6
     c->timing.kernel_ms = ms;
     c->timing.points = n;
     return errbits_to_code(bits, err);
+}
+
+int ptau_subgroup_check(int curve, int group, const uint8_t *in, int compressed_in, uint64_t n, int device, char *errbuf,
+                        size_t err_len) {
+    Err err{errbuf, err_len};
+    const GroupOps *ops = get_ops(curve, group);
+    if (!ops) return err.fail(PTAU_E_ARG, "unknown curve/group %d/%d", curve, group);
+    if (n && !in) return err.fail(PTAU_E_ARG, "null pointer argument");
+    DeviceCtx *c;
+    int rc = ensure_ctx(device, c, err);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(hipSetDevice(device));
+    c->timing = ptau_timing{};
+    if (!n) return PTAU_OK;
+    const size_t isz = compressed_in ? ops->comp : ops->uncomp;
+    if ((rc = grow(c->d_in, c->in_cap, n * isz, err))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_in, in, n * isz, hipMemcpyHostToDevice, c->stream));
+    return run_subgroup_check_dev(c, curve, group, ops, (const uint8_t *)c->d_in, compressed_in, n, err);
+}
+
+int ptau_verify_chunk(const ptau_params *p, const uint8_t *challenge, size_t challenge_len, const uint8_t *response,
+                      size_t response_len, uint8_t *new_challenge, size_t new_challenge_len, int check_input,
+                      int check_output, int subgroup_check_mode, int ratio_check, int device, char *errbuf, size_t err_len) {
+    Err err{errbuf, err_len};
+    int rc = check_params(p, err);
+    if (rc) return rc;
+    if (!challenge || !response || !new_challenge) return err.fail(PTAU_E_ARG, "null pointer argument");
+    ptau_sizes sz;
+    ptau_params_sizes(p, &sz);
+    if (challenge_len != sz.accumulator_size || new_challenge_len != sz.accumulator_size)
+        return err.fail(PTAU_E_LEN, "challenge / new challenge must be %llu bytes", (unsigned long long)sz.accumulator_size);
+    if (response_len != sz.contribution_size)
+        return err.fail(PTAU_E_LEN, "response is %zu bytes, parameters require %llu", response_len,
+                        (unsigned long long)sz.contribution_size);
+    if (ratio_check)
+        return err.fail(PTAU_E_UNSUPPORTED, "ratio_check needs the pairing tail (ptau_check_same_ratio): not built yet");
+    // hash chain: response[0..64) must be BLAKE2b(challenge)
+    uint8_t digest[64];
+    ptau_blake2b512(challenge, challenge_len, digest);
+    if (memcmp(digest, response, 64) != 0)
+        return err.fail(PTAU_E_HASH_CHAIN, "response does not start with the hash of the challenge it claims to extend");
+    const GroupOps *g1 = get_ops(p->curve, 1), *g2 = get_ops(p->curve, 2);
+    DeviceCtx *c;
+    if ((rc = ensure_ctx(device, c, err))) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(hipSetDevice(device));
+    c->timing = ptau_timing{};
+    (void)check_input;   // DEFAULT_VERIFY_CHECK_INPUT_CORRECTNESS = No: the challenge was produced by this verifier
+    const uint64_t n1 = sz.g1_chunk_size, n2 = sz.other_chunk_size;
+    const uint8_t *pi = response + 64;
+    uint8_t *po = new_challenge + 64;
+    struct { const GroupOps *ops; int group; uint64_t n; } vec[5] = {{g1, 1, n1}, {g2, 2, n2}, {g1, 1, n2}, {g1, 1, n2}, {g2, 2, 1}};
+    for (auto &v : vec) {
+        if ((rc = run_verify_vector(c, p->curve, v.group, v.ops, pi, po, v.n, check_output, subgroup_check_mode, err))) return rc;
+        pi += v.n * v.ops->comp;
+        po += v.n * v.ops->uncomp;
+    }
+    // new_challenge = BLAKE2b(response) | decompressed elements
+    ptau_blake2b512(response, response_len, new_challenge);
+    return PTAU_OK;
+}
+
+int ptau_transform_pok_and_correctness_file(const ptau_params *p, const char *challenge_path, const char *challenge_hash_path,
+                                            int check_input, const char *response_path, const char *response_hash_path,
+                                            int check_output, const char *new_challenge_path,
+                                            const char *new_challenge_hash_path, int subgroup_check_mode, int ratio_check,
+                                            int device, char *errbuf, size_t err_len) {
+    Err err{errbuf, err_len};
+    int rc = check_params(p, err);
+    if (rc) return rc;
+    if (!challenge_path || !challenge_hash_path || !response_path || !response_hash_path || !new_challenge_path ||
+        !new_challenge_hash_path)
+        return err.fail(PTAU_E_ARG, "null pointer argument");
+    ptau_sizes sz;
+    ptau_params_sizes(p, &sz);
+    MappedFile ch, resp, nc;
+    if ((rc = ch.open_ro(challenge_path, err))) return rc;
+    if ((rc = resp.open_ro(response_path, err))) return rc;
+    if (ch.len != sz.accumulator_size || resp.len != sz.contribution_size)
+        return err.fail(PTAU_E_LEN, "challenge/response file sizes %zu/%zu do not match the parameters (%llu/%llu)", ch.len,
+                        resp.len, (unsigned long long)sz.accumulator_size, (unsigned long long)sz.contribution_size);
+    uint8_t digest[64];
+    ptau_blake2b512((const uint8_t *)ch.p, ch.len, digest);
+    if ((rc = write_small_file(challenge_hash_path, digest, 64, err))) return rc;
+    ptau_blake2b512((const uint8_t *)resp.p, resp.len, digest);
+    if ((rc = write_small_file(response_hash_path, digest, 64, err))) return rc;
+    if ((rc = nc.create_new(new_challenge_path, sz.accumulator_size, err))) return rc;
+    if ((rc = ptau_verify_chunk(p, (const uint8_t *)ch.p, ch.len, (const uint8_t *)resp.p, resp.len, (uint8_t *)nc.p, nc.len,
+                                check_input, check_output, subgroup_check_mode, ratio_check, device, errbuf, err_len)))
+        return rc;
+    ptau_blake2b512((const uint8_t *)nc.p, nc.len, digest);
+    if (msync(nc.p, nc.len, MS_SYNC)) return err.fail(PTAU_E_IO, "msync failed: %s", strerror(errno));
+    return write_small_file(new_challenge_hash_path, digest, 64, err);
 }
 
 }  // extern "C"

@@ -123,7 +123,7 @@ constexpr int WINDOW_ENTRIES = 8;
 template <class G>
 PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typename G::J *scratch,
                                      typename G::J *wtab, uint64_t n, uint64_t i, const uint32_t *table,
-                                     int check_input) {
+                                     int check_input, const uint32_t *fixed_scalar = nullptr) {
     using Fr = typename G::Fr;
     using F = typename G::F;
     using A = typename G::A;
@@ -145,9 +145,14 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
         cur = J::add_mixed(cur, p);
         wtab[(uint64_t)e * n + i] = cur;
     }
-    Fr ek = scalar_for_index<Fr>(table, i);
     uint32_t k[NL];
-    ek.to_canonical(k);
+    if (fixed_scalar) {   // one public scalar for every point (subgroup check with the group order)
+#pragma unroll
+        for (int j = 0; j < NL; j++) k[j] = fixed_scalar[j];
+    } else {
+        Fr ek = scalar_for_index<Fr>(table, i);
+        ek.to_canonical(k);
+    }
     uint32_t c = 0;
 #pragma unroll
     for (int j = 0; j < NL; j++) k[j] = addc(k[j], 0x88888888u, c);
@@ -176,10 +181,28 @@ template <class G>
 __global__ void __launch_bounds__(256)
 window_scalar_mul_kernel(const uint8_t *__restrict__ in, int compressed_in, typename G::J *__restrict__ scratch,
                          typename G::J *__restrict__ wtab, uint64_t n, const uint32_t *__restrict__ table,
-                         int check_input, int *__restrict__ err) {
+                         int check_input, const uint32_t *__restrict__ fixed_scalar, int *__restrict__ err) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    int bad = window_scalar_mul_thread<G>(in, compressed_in, scratch, wtab, n, i, table, check_input);
+    int bad = window_scalar_mul_thread<G>(in, compressed_in, scratch, wtab, n, i, table, check_input, fixed_scalar);
+    if (bad) atomicOr(err, bad);
+}
+
+// y^2 == x^3 + a x + b for uncompressed inputs (compressed reads are on the curve by construction)
+template <class G>
+PTAU_HD int on_curve_thread(const uint8_t *in, uint64_t i) {
+    using F = typename G::F;
+    typename G::A p;
+    if (!read_uncompressed<F>(in + i * G::UNCOMP, p)) return ERRBIT_NONCANONICAL;
+    if (p.inf) return 0;
+    return F::sqr(p.y) == curve_rhs<F, typename G::J::CfgT>(p.x) ? 0 : ERRBIT_NOT_ON_CURVE;
+}
+template <class G>
+__global__ void __launch_bounds__(256)
+on_curve_kernel(const uint8_t *__restrict__ in, uint64_t n, int *__restrict__ err) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int bad = on_curve_thread<G>(in, i);
     if (bad) atomicOr(err, bad);
 }
 
@@ -310,7 +333,8 @@ struct GroupOps {
     void (*scalar_mul)(hipStream_t, const uint8_t *in, int cin, void *scratch, uint64_t n, const uint32_t *table,
                        int check_input, int *err);
     void (*window_scalar_mul)(hipStream_t, const uint8_t *in, int cin, void *scratch, void *wtab, uint64_t n,
-                              const uint32_t *table, int check_input, int *err);
+                              const uint32_t *table, int check_input, const uint32_t *fixed_scalar, int *err);
+    void (*on_curve)(hipStream_t, const uint8_t *in, uint64_t n, int *err);
     void (*fixed_scalar_mul)(hipStream_t, const uint8_t *in, int cin, void *scratch, uint64_t n,
                              const uint32_t *scalar, int nbits, int *err);
     void (*normalize)(hipStream_t, const void *scratch, void *pre, uint8_t *out, int cout, uint64_t n, uint64_t T,
@@ -354,10 +378,14 @@ struct Launch {
                            check_input, err);
     }
     static void window_scalar_mul(hipStream_t s, const uint8_t *in, int cin, void *scratch, void *wtab, uint64_t n,
-                                  const uint32_t *table, int check_input, int *err) {
+                                  const uint32_t *table, int check_input, const uint32_t *fixed_scalar, int *err) {
         if (!n) return;
         hipLaunchKernelGGL(window_scalar_mul_kernel<G>, grid(n), dim3(256), 0, s, in, cin, (typename G::J *)scratch,
-                           (typename G::J *)wtab, n, table, check_input, err);
+                           (typename G::J *)wtab, n, table, check_input, fixed_scalar, err);
+    }
+    static void on_curve(hipStream_t s, const uint8_t *in, uint64_t n, int *err) {
+        if (!n) return;
+        hipLaunchKernelGGL(on_curve_kernel<G>, grid(n), dim3(256), 0, s, in, n, err);
     }
     static void fixed_scalar_mul(hipStream_t s, const uint8_t *in, int cin, void *scratch, uint64_t n,
                                  const uint32_t *scalar, int nbits, int *err) {
@@ -390,6 +418,7 @@ struct Launch {
         o.build_table = build_table;
         o.scalar_mul = scalar_mul;
         o.window_scalar_mul = window_scalar_mul;
+        o.on_curve = on_curve;
         o.fixed_scalar_mul = fixed_scalar_mul;
         o.normalize = normalize;
         o.expect_infinity = expect_infinity;

@@ -203,6 +203,43 @@ def decompress(curve, group, data: bytes, n, check_output=CheckForCorrectness.No
     return out.raw[:n * L.ptau_point_size(c, group, 0)]
 
 
+def subgroup_check(curve, group, data: bytes, n, compressed_in=False, device=0) -> None:
+    """setup-utils check_subgroup (Direct) + on-curve; raises PtauError(-5 / -3) like the reference panics."""
+    L = _lib.load_library()
+    c = curve_from_str(curve) if isinstance(curve, str) else int(curve)
+    eb = _lib.errbuf()
+    _lib.check(L.ptau_subgroup_check(c, group, data, int(compressed_in), n, device, eb, len(eb)), eb)
+
+
+def verification_and_decompress(challenge: bytes, response: bytes, parameters: Phase1Parameters,
+                                check_input=CheckForCorrectness.No, check_output=CheckForCorrectness.OnlyNonZero,
+                                subgroup_check_mode=SubgroupCheckMode.Auto, ratio_check=False, device=0) -> bytes:
+    """Element part of Phase1::verification + Phase1::decompress on in-memory buffers; returns new_challenge."""
+    L = _lib.load_library()
+    out = ctypes.create_string_buffer(parameters.accumulator_size)
+    eb = _lib.errbuf()
+    rc = L.ptau_verify_chunk(ctypes.byref(parameters._c()), challenge, len(challenge), response, len(response), out, len(out),
+                             int(check_input), int(check_output), int(subgroup_check_mode), int(bool(ratio_check)), device,
+                             eb, len(eb))
+    _lib.check(rc, eb)
+    return out.raw
+
+
+def transform_pok_and_correctness(challenge_filename, challenge_hash_filename, check_input_correctness, response_filename,
+                                  response_hash_filename, check_output_correctness, new_challenge_filename,
+                                  new_challenge_hash_filename, subgroup_check_mode, ratio_check,
+                                  parameters: Phase1Parameters, device: int = 0):
+    """phase1_cli::transform_pok_and_correctness (contribute.rs:968-986), same argument order."""
+    L = _lib.load_library()
+    eb = _lib.errbuf()
+    rc = L.ptau_transform_pok_and_correctness_file(
+        ctypes.byref(parameters._c()), os.fsencode(challenge_filename), os.fsencode(challenge_hash_filename),
+        int(check_input_correctness), os.fsencode(response_filename), os.fsencode(response_hash_filename),
+        int(check_output_correctness), os.fsencode(new_challenge_filename), os.fsencode(new_challenge_hash_filename),
+        int(subgroup_check_mode), int(bool(ratio_check)), device, eb, len(eb))
+    _lib.check(rc, eb)
+
+
 def last_timing(device=0):
     t = _lib.ptau_timing()
     _lib.load_library().ptau_last_timing(device, ctypes.byref(t))

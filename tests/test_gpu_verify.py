@@ -1,0 +1,146 @@
+"""GPU parity tests of the verify path (transform_pok_and_correctness element checks + decompress),
+through the C ABI, against the oracle and the golden fixtures."""
+import random
+
+import pytest
+
+from conftest import CURVE_NAMES
+from oracle.pyref import phase1 as P, serde
+from oracle.pyref.curves import CURVES
+from oracle.pyref.ec import Group
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(pkg, name, doc, idx):
+    return pkg.Phase1Parameters.new_chunk(name, 0, idx, doc["chunk_size"], 0, doc["power"], doc["batch_size"])
+
+
+def _off_subgroup_point(G, rng):
+    """A curve point outside the prime-order subgroup (exists when the cofactor is > 1)."""
+    F = G.F
+    while True:
+        x = tuple(rng.randrange(G.curve.q) for _ in range(F.deg))
+        rhs = F.add(F.add(F.mul(F.sqr(x), x), F.mul(G.a, x)), G.b)
+        y = F.sqrt(rhs)
+        if y is not None and not G.in_subgroup((x, y)):
+            return (x, y)
+
+
+@pytest.mark.parametrize("name", CURVE_NAMES)
+def test_verify_golden_chunks(name, pkg, golden, cref):
+    doc = golden[name]
+    for ch in doc["chunks"]:
+        prm = _params(pkg, name, doc, ch["chunk_index"])
+        challenge, response = bytes.fromhex(ch["challenge"]), bytes.fromhex(ch["response"])
+        nc = pkg.phase1_cli.verification_and_decompress(challenge, response, prm)
+        assert pkg.calculate_hash(nc).hex() == ch["new_challenge_hash"]
+        assert nc[:64] == bytes.fromhex(ch["response_hash"])
+        # the oracle's decompress gives the same bytes
+        p = P.Params(CURVES[name], P.CHUNKED, ch["chunk_index"], doc["chunk_size"], doc["power"], doc["batch_size"])
+        assert nc == P.new_challenge_from_response(p, response)
+
+
+@pytest.mark.parametrize("name", CURVE_NAMES)
+def test_verify_rejects_bad_inputs(name, pkg, golden):
+    doc = golden[name]
+    ch = doc["chunks"][0]
+    c = CURVES[name]
+    prm = _params(pkg, name, doc, 0)
+    challenge, response = bytes.fromhex(ch["challenge"]), bytearray.fromhex(ch["response"])
+    # 1. broken hash chain
+    bad_ch = bytearray(challenge)
+    bad_ch[100] ^= 1
+    with pytest.raises(pkg.PtauError) as e:
+        pkg.phase1_cli.verification_and_decompress(bytes(bad_ch), bytes(response), prm)
+    assert e.value.code == -7
+    # 2. point at infinity in the response (OnlyNonZero is the verifier's default output check)
+    G1 = Group(c, 1)
+    r2 = bytearray(response)
+    r2[64:64 + G1.comp_size] = serde.write_point(G1, None, True)
+    with pytest.raises(pkg.PtauError) as e:
+        pkg.phase1_cli.verification_and_decompress(challenge, bytes(r2), prm)
+    assert e.value.code == -4
+    # 3. element outside the prime-order subgroup (G1 where the cofactor allows it, else G2)
+    rng = random.Random(99)
+    grp = 2 if name.startswith("mnt") else 1
+    G = Group(c, grp)
+    bad_pt = serde.write_point(G, _off_subgroup_point(G, rng), True)
+    p = P.Params(c, P.CHUNKED, 0, doc["chunk_size"], doc["power"], doc["batch_size"])
+    off = {nm: o for (nm, g, o, cnt) in p.layout(True)[0]}["tau_g1" if grp == 1 else "tau_g2"]
+    r3 = bytearray(response)
+    r3[off + G.comp_size:off + 2 * G.comp_size] = bad_pt
+    with pytest.raises(pkg.PtauError) as e:
+        pkg.phase1_cli.verification_and_decompress(challenge, bytes(r3), prm)
+    assert e.value.code == -5
+    # ... and accepted when the subgroup check is switched off (SubgroupCheckMode::No)
+    nc = pkg.phase1_cli.verification_and_decompress(challenge, bytes(r3), prm, subgroup_check_mode=pkg.SubgroupCheckMode.No)
+    assert len(nc) == prm.accumulator_size
+    # 4. wrong sizes
+    with pytest.raises(pkg.PtauError) as e:
+        pkg.phase1_cli.verification_and_decompress(challenge + b"\0", bytes(response), prm)
+    assert e.value.code == -2
+
+
+@pytest.mark.parametrize("name", CURVE_NAMES)
+def test_subgroup_check_api(name, pkg):
+    c = CURVES[name]
+    rng = random.Random(5)
+    for grp in (1, 2):
+        G = Group(c, grp)
+        good = [G.mul(G.gen, rng.randrange(1, c.r)) for _ in range(5)] + [None]
+        for comp in (False, True):
+            pkg.phase1_cli.subgroup_check(name, grp, serde.write_batch(G, good, comp), len(good), compressed_in=comp)
+        if not (name.startswith("mnt") and grp == 1):
+            bad = good[:3] + [_off_subgroup_point(G, rng)] + good[3:]
+            for comp in (False, True):
+                with pytest.raises(pkg.PtauError) as e:
+                    pkg.phase1_cli.subgroup_check(name, grp, serde.write_batch(G, bad, comp), len(bad), compressed_in=comp)
+                assert e.value.code == -5
+        # uncompressed point that is not on the curve: y + 1
+        x, y = good[0]
+        off = serde.write_point(G, (x, G.F.add(y, G.F.one())), False)
+        with pytest.raises(pkg.PtauError) as e:
+            pkg.phase1_cli.subgroup_check(name, grp, off, 1, compressed_in=False)
+        assert e.value.code == -3
+
+
+def test_transform_pok_and_correctness_files(pkg, golden, tmp_path):
+    name = "bls12_377"
+    doc = golden[name]
+    ch = doc["chunks"][0]
+    prm = _params(pkg, name, doc, 0)
+    f = {k: str(tmp_path / k) for k in ("challenge", "challenge.hash", "response", "response.hash", "new_challenge", "new_challenge.hash")}
+    open(f["challenge"], "wb").write(bytes.fromhex(ch["challenge"]))
+    open(f["response"], "wb").write(bytes.fromhex(ch["response"]))
+    pkg.transform_pok_and_correctness(f["challenge"], f["challenge.hash"], pkg.CheckForCorrectness.No, f["response"],
+                                      f["response.hash"], pkg.CheckForCorrectness.OnlyNonZero, f["new_challenge"],
+                                      f["new_challenge.hash"], pkg.SubgroupCheckMode.Auto, False, prm)
+    assert open(f["challenge.hash"], "rb").read().hex() == ch["challenge_hash"]
+    assert open(f["response.hash"], "rb").read().hex() == ch["response_hash"]
+    assert open(f["new_challenge.hash"], "rb").read().hex() == ch["new_challenge_hash"]
+    nc = open(f["new_challenge"], "rb").read()
+    assert pkg.calculate_hash(nc).hex() == ch["new_challenge_hash"]
+
+
+def test_contribute_verify_round_trip_2pow12(pkg, cref):
+    """BASELINE config #1 shape (BLS12-377, power 12, chunk 2^10): contribute then verify chunk 0 and a
+    tauG1-only chunk; the verifier's new challenge must be the decompressed response (oracle-checked on a sample)."""
+    name = "bls12_377"
+    c = CURVES[name]
+    rng = random.Random(12)
+    for idx in (0, 5):
+        p = P.Params(c, P.CHUNKED, idx, 1 << 10, 12, 1 << 10)
+        prm = pkg.Phase1Parameters.new_chunk(name, 0, idx, 1 << 10, 0, 12, 1 << 10)
+        ch0 = P.initialization(p)
+        key = pkg.PrivateKey(rng.randrange(c.r), rng.randrange(c.r), rng.randrange(c.r), bytes(prm.public_key_size))
+        resp = bytearray(pkg.phase1_cli.computation(ch0, prm, key))
+        resp[:64] = pkg.calculate_hash(ch0)
+        nc = pkg.phase1_cli.verification_and_decompress(ch0, bytes(resp), prm)
+        assert nc[:64] == pkg.calculate_hash(bytes(resp))
+        ref = cref.computation(name, 0, idx, 1 << 10, 12, ch0, key.tau, key.alpha, key.beta, nthreads=8)
+        end = prm.contribution_size - prm.public_key_size
+        assert bytes(resp[64:end]) == ref[64:end]
+        G1 = Group(c, 1)
+        n1 = p.g1_chunk_size
+        assert nc[64:64 + n1 * 96] == cref.decompress(name, 1, bytes(resp[64:64 + n1 * 48]), n1, nthreads=8)
