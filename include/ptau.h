@@ -161,6 +161,19 @@ int ptau_transform_pok_and_correctness_file(const ptau_params *p, const char *ch
                                             const char *new_challenge_path, const char *new_challenge_hash_path,
                                             int subgroup_check_mode, int ratio_check, int device, char *err, size_t err_len);
 
+/* setup_utils::dense_multiexp — sum_i scalars[i] * in[i] -> one serialized point (host buffers; scalars are
+ * n x ptau_fr_limbs(curve) canonical limbs).  Used inside merge_pairs / power_pairs. */
+int ptau_msm(int curve, int group, const uint8_t *in, int compressed_in, uint64_t n, const uint64_t *scalars,
+             uint8_t *out, int compressed_out, int device, char *err, size_t err_len);
+
+/* setup_utils::power_pairs (inside check_power_ratios; reference call sites src/bin/verify_transcript.rs:812-822,
+ * src/bin/control.rs:587-591): with random coefficients rho_i,
+ *     out_a = sum_{i<n-1} rho_i * in[i],   out_b = sum_{i<n-1} rho_i * in[i+1]      (both UNCOMPRESSED).
+ * rho_i comes from a counter-based generator keyed by `seed` (16 bytes; NULL = fresh OS entropy) and the GLOBAL
+ * element index index_base + i, so slices of one vector processed on different GPUs use one rho stream (row C1). */
+int ptau_power_pairs(int curve, int group, const uint8_t *in, int compressed_in, uint64_t n, const uint8_t seed[16],
+                     uint64_t index_base, uint8_t *out_a, uint8_t *out_b, int device, char *err, size_t err_len);
+
 /* Timings of the most recent compute call on `device`. */
 int ptau_last_timing(int device, ptau_timing *out);
 

@@ -144,7 +144,8 @@ int run_apply_powers_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in,
         HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
         HIP_TRY(hipEventRecord(c->ev[0], c->stream));
         if (windowed)
-            ops->window_scalar_mul(c->stream, d_in + off * isz, cin, c->scratch, c->wtab, m, c->d_table, check_input, nullptr, c->d_err);
+            ops->window_scalar_mul(c->stream, d_in + off * isz, cin, c->scratch, c->wtab, m,
+                                   ptau::ScalarSource{ptau::SCALAR_TAU_TABLE, c->d_table, 0, 0, 0}, check_input, c->d_err);
         else
             ops->scalar_mul(c->stream, d_in + off * isz, cin, c->scratch, m, c->d_table, check_input, c->d_err);
         HIP_TRY(hipEventRecord(c->ev[1], c->stream));
@@ -218,7 +219,8 @@ int run_subgroup_check_dev(DeviceCtx *c, int curve, int group, const GroupOps *o
             int rc;
             if ((rc = grow(c->scratch, c->scratch_cap, m * ops->jac_bytes, err))) return rc;
             if ((rc = grow(c->wtab, c->wtab_cap, m * ptau::WINDOW_ENTRIES * ops->jac_bytes, err))) return rc;
-            ops->window_scalar_mul(c->stream, d_in + off * isz, cin, c->scratch, c->wtab, m, c->d_table, 0, c->d_table, c->d_err);
+            ops->window_scalar_mul(c->stream, d_in + off * isz, cin, c->scratch, c->wtab, m,
+                                   ptau::ScalarSource{ptau::SCALAR_FIXED, c->d_table, 0, 0, 0}, 0, c->d_err);
             ops->expect_infinity(c->stream, c->scratch, m, c->d_err);
         }
     }
@@ -271,6 +273,62 @@ int run_verify_vector(DeviceCtx *c, int curve, int group, const GroupOps *ops, c
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
     c->timing.d2h_ms += ms;
     return PTAU_OK;
+}
+
+// sum_i k_i * P_i over n device-resident points -> ONE serialized affine point in host memory.
+// Round-1 form: n windowed scalar multiplications (the K1 kernel) followed by a tree of Jacobian sums;
+// a bucket (Pippenger) accumulation is the planned replacement.  Caller holds the device mutex.
+int run_msm_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, int cin, uint64_t n, ptau::ScalarSource src,
+                uint8_t *out_host, int cout, const Err &err) {
+    const int isz = cin ? ops->comp : ops->uncomp, osz = cout ? ops->comp : ops->uncomp;
+    const uint64_t launch_cap =
+        std::max<uint64_t>(256, std::min(MAX_LAUNCH_POINTS, MAX_WINDOW_TABLE_BYTES / (ptau::WINDOW_ENTRIES * ops->jac_bytes)));
+    int rc;
+    const uint64_t nlaunch = n ? (n + launch_cap - 1) / launch_cap : 1;
+    // partial sums: one Jacobian per launch, kept at the tail of the scratch area
+    if ((rc = grow(c->scratch, c->scratch_cap, (std::min(n, launch_cap) + 4096 + nlaunch + 8) * ops->jac_bytes, err))) return rc;
+    if ((rc = grow(c->pre, c->pre_cap, 16 * ops->fe_bytes, err))) return rc;
+    uint8_t *S = (uint8_t *)c->scratch;
+    const uint64_t cap = std::min(n, launch_cap);
+    uint8_t *level = S + cap * ops->jac_bytes;                       // 4096 partials
+    uint8_t *totals = level + 4096 * ops->jac_bytes;                 // nlaunch partial totals (+ final)
+    HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
+    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    uint64_t li = 0;
+    for (uint64_t off = 0; off < n; off += launch_cap, li++) {
+        const uint64_t m = std::min(launch_cap, n - off);
+        if ((rc = grow(c->wtab, c->wtab_cap, m * ptau::WINDOW_ENTRIES * ops->jac_bytes, err))) return rc;
+        ptau::ScalarSource s2 = src;
+        if (s2.mode == ptau::SCALAR_ARRAY) s2.ptr += off * ops->fr_limbs32;
+        s2.index_base += off;
+        ops->window_scalar_mul(c->stream, d_in + off * isz, cin, S, c->wtab, m, s2, 0, c->d_err);
+        // tree: m -> min(m,4096)·.. -> 64 -> 1
+        const uint64_t t1 = std::min<uint64_t>(4096, (m + 15) / 16);
+        ops->reduce_sum(c->stream, S, level, m, t1);
+        const uint64_t t2 = std::min<uint64_t>(64, t1);
+        ops->reduce_sum(c->stream, level, S, t1, t2);               // reuse the head of S for level 2
+        ops->reduce_sum(c->stream, S, totals + li * ops->jac_bytes, t2, 1);
+    }
+    if (n == 0) {
+        ops->reduce_sum(c->stream, S, totals, 0, 1);                // empty sum = infinity
+        li = 1;
+    }
+    ops->reduce_sum(c->stream, totals, totals + nlaunch * ops->jac_bytes, li, 1);
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    // normalise + serialise the single result
+    if ((rc = grow(c->d_out, c->out_cap, std::max<size_t>(c->out_cap, 2 * ops->uncomp), err))) return rc;
+    ops->normalize(c->stream, totals + nlaunch * ops->jac_bytes, c->pre, (uint8_t *)c->d_out, cout, 1, 1, 0, c->d_err);
+    int bits = 0;
+    HIP_TRY(hipMemcpyAsync(&bits, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(out_host, c->d_out, osz, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    c->timing.kernel_ms += ms;
+    c->timing.scalar_mul_ms += ms;
+    c->timing.points += n;
+    return errbits_to_code(bits, err);
 }
 
 int check_params(const ptau_params *p, const Err &err) {
@@ -708,6 +766,67 @@ int ptau_transform_pok_and_correctness_file(const ptau_params *p, const char *ch
     ptau_blake2b512((const uint8_t *)nc.p, nc.len, digest);
     if (msync(nc.p, nc.len, MS_SYNC)) return err.fail(PTAU_E_IO, "msync failed: %s", strerror(errno));
     return write_small_file(new_challenge_hash_path, digest, 64, err);
+}
+
+int ptau_msm(int curve, int group, const uint8_t *in, int compressed_in, uint64_t n, const uint64_t *scalars, uint8_t *out,
+             int compressed_out, int device, char *errbuf, size_t err_len) {
+    Err err{errbuf, err_len};
+    const GroupOps *ops = get_ops(curve, group);
+    if (!ops) return err.fail(PTAU_E_ARG, "unknown curve/group %d/%d", curve, group);
+    if (!out || (n && (!in || !scalars))) return err.fail(PTAU_E_ARG, "null pointer argument");
+    DeviceCtx *c;
+    int rc = ensure_ctx(device, c, err);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(hipSetDevice(device));
+    c->timing = ptau_timing{};
+    const size_t isz = compressed_in ? ops->comp : ops->uncomp;
+    const int nl64 = (ops->fr_limbs32 + 1) / 2;
+    // scalars travel as 32-bit limbs; Fr of BLS12-377 has 8 of them, the 753-bit fields 24
+    std::vector<uint32_t> k32((size_t)n * ops->fr_limbs32);
+    for (uint64_t i = 0; i < n; i++)
+        for (int j = 0; j < ops->fr_limbs32; j++) k32[i * ops->fr_limbs32 + j] = (uint32_t)(scalars[i * nl64 + j / 2] >> (32 * (j & 1)));
+    if ((rc = grow(c->d_in, c->in_cap, std::max<size_t>(1, n * isz + k32.size() * 4 + 16), err))) return rc;
+    uint8_t *d_pts = (uint8_t *)c->d_in;
+    uint32_t *d_k = (uint32_t *)(d_pts + ((n * isz + 15) / 16) * 16);
+    if (n) {
+        HIP_TRY(hipMemcpyAsync(d_pts, in, n * isz, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_k, k32.data(), k32.size() * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    return run_msm_dev(c, ops, d_pts, compressed_in, n, ptau::ScalarSource{ptau::SCALAR_ARRAY, d_k, 0, 0, 0}, out, compressed_out, err);
+}
+
+int ptau_power_pairs(int curve, int group, const uint8_t *in, int compressed_in, uint64_t n, const uint8_t seed[16],
+                     uint64_t index_base, uint8_t *out_a, uint8_t *out_b, int device, char *errbuf, size_t err_len) {
+    Err err{errbuf, err_len};
+    const GroupOps *ops = get_ops(curve, group);
+    if (!ops) return err.fail(PTAU_E_ARG, "unknown curve/group %d/%d", curve, group);
+    if (!in || !out_a || !out_b) return err.fail(PTAU_E_ARG, "null pointer argument");
+    if (n < 2) return err.fail(PTAU_E_ARG, "power_pairs needs at least two elements");
+    uint64_t s[2];
+    if (seed) {
+        memcpy(s, seed, 16);
+    } else {   // per-verification secret from the OS
+        FILE *f = fopen("/dev/urandom", "rb");
+        if (!f || fread(s, 1, 16, f) != 16) {
+            if (f) fclose(f);
+            return err.fail(PTAU_E_IO, "cannot read /dev/urandom for the random linear combination");
+        }
+        fclose(f);
+    }
+    DeviceCtx *c;
+    int rc = ensure_ctx(device, c, err);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(hipSetDevice(device));
+    c->timing = ptau_timing{};
+    const size_t isz = compressed_in ? ops->comp : ops->uncomp;
+    if ((rc = grow(c->d_in, c->in_cap, n * isz, err))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_in, in, n * isz, hipMemcpyHostToDevice, c->stream));
+    const ptau::ScalarSource src{ptau::SCALAR_PRF, nullptr, s[0], s[1], index_base};
+    // (sum rho_i P_i, sum rho_i P_{i+1}), i in [0, n-1): the same coefficients on the vector and on its shift
+    if ((rc = run_msm_dev(c, ops, (const uint8_t *)c->d_in, compressed_in, n - 1, src, out_a, 0, err))) return rc;
+    return run_msm_dev(c, ops, (const uint8_t *)c->d_in + isz, compressed_in, n - 1, src, out_b, 0, err);
 }
 
 }  // extern "C"

@@ -117,13 +117,35 @@ scalar_mul_kernel(const uint8_t *__restrict__ in, int compressed_in, typename G:
 // cheap on a 288 GB part and the live working set (resident waves only) sits in the Infinity Cache.
 // Digits: d_w = nibble_w(k + 0x88..8) - 8 in [-8, 7], so any digit is available MSB-first without a
 // carry pass.  Table layout is entry-major, table[e * n + i], so lanes holding the same digit coalesce.
+// Where a thread's scalar comes from.
+enum : int { SCALAR_TAU_TABLE = 0, SCALAR_FIXED = 1, SCALAR_ARRAY = 2, SCALAR_PRF = 3 };
+struct ScalarSource {
+    int mode;
+    const uint32_t *ptr;      // TAU_TABLE: the tau^(2^k) table; FIXED: NL canonical limbs; ARRAY: n x NL canonical limbs
+    uint64_t seed0, seed1;    // PRF: 128-bit seed
+    uint64_t index_base;      // PRF: global index of element 0 (slices of one vector agree across GPUs)
+};
+
+PTAU_HD uint64_t splitmix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// word j of the random coefficient rho_idx of merge_pairs / power_pairs (setup-utils draws Fr::rand from
+// thread_rng; here a counter-based generator keyed by a per-verification 128-bit secret, so that any slice
+// of a vector, on any GPU, sees the same rho for the same global index).  rho < 2^(BITS-1) < r.
+PTAU_HD uint32_t prf_word(uint64_t seed0, uint64_t seed1, uint64_t idx, int nl, int j) {
+    uint64_t z = splitmix64(seed0 + (idx * (uint64_t)nl + (uint64_t)j + 1) * 0x9E3779B97F4A7C15ull) ^ seed1;
+    return (uint32_t)(splitmix64(z) >> 32);
+}
+
 constexpr int WINDOW_BITS = 4;
 constexpr int WINDOW_ENTRIES = 8;
 
 template <class G>
 PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typename G::J *scratch,
-                                     typename G::J *wtab, uint64_t n, uint64_t i, const uint32_t *table,
-                                     int check_input, const uint32_t *fixed_scalar = nullptr) {
+                                     typename G::J *wtab, uint64_t n, uint64_t i, const ScalarSource &src,
+                                     int check_input) {
     using Fr = typename G::Fr;
     using F = typename G::F;
     using A = typename G::A;
@@ -146,11 +168,19 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
         wtab[(uint64_t)e * n + i] = cur;
     }
     uint32_t k[NL];
-    if (fixed_scalar) {   // one public scalar for every point (subgroup check with the group order)
+    if (src.mode == SCALAR_FIXED) {          // one public scalar for every point (subgroup check: the group order)
 #pragma unroll
-        for (int j = 0; j < NL; j++) k[j] = fixed_scalar[j];
+        for (int j = 0; j < NL; j++) k[j] = src.ptr[j];
+    } else if (src.mode == SCALAR_ARRAY) {   // explicit per-point scalars (MSM with caller-supplied coefficients)
+#pragma unroll
+        for (int j = 0; j < NL; j++) k[j] = src.ptr[i * NL + j];
+    } else if (src.mode == SCALAR_PRF) {     // random linear combination coefficients
+        constexpr int TOPBITS = (Fr::Params::BITS - 1) - 32 * (NL - 1);   // bits kept in the top limb
+#pragma unroll
+        for (int j = 0; j < NL; j++) k[j] = prf_word(src.seed0, src.seed1, src.index_base + i, NL, j);
+        k[NL - 1] &= (TOPBITS >= 32) ? 0xffffffffu : ((1u << TOPBITS) - 1u);
     } else {
-        Fr ek = scalar_for_index<Fr>(table, i);
+        Fr ek = scalar_for_index<Fr>(src.ptr, i);
         ek.to_canonical(k);
     }
     uint32_t c = 0;
@@ -180,12 +210,28 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
 template <class G>
 __global__ void __launch_bounds__(256)
 window_scalar_mul_kernel(const uint8_t *__restrict__ in, int compressed_in, typename G::J *__restrict__ scratch,
-                         typename G::J *__restrict__ wtab, uint64_t n, const uint32_t *__restrict__ table,
-                         int check_input, const uint32_t *__restrict__ fixed_scalar, int *__restrict__ err) {
+                         typename G::J *__restrict__ wtab, uint64_t n, ScalarSource src, int check_input,
+                         int *__restrict__ err) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    int bad = window_scalar_mul_thread<G>(in, compressed_in, scratch, wtab, n, i, table, check_input, fixed_scalar);
+    int bad = window_scalar_mul_thread<G>(in, compressed_in, scratch, wtab, n, i, src, check_input);
     if (bad) atomicOr(err, bad);
+}
+
+// Sum of Jacobian points: thread t adds elements t, t+T, t+2T, ... (< n) into out[t]  (one tree level)
+template <class G>
+PTAU_HD void reduce_sum_thread(const typename G::J *in, typename G::J *out, uint64_t n, uint64_t T, uint64_t t) {
+    using J = typename G::J;
+    J acc = J::infinity();
+    for (uint64_t i = t; i < n; i += T) acc = J::add(acc, in[i]);
+    out[t] = acc;
+}
+template <class G>
+__global__ void __launch_bounds__(256)
+reduce_sum_kernel(const typename G::J *__restrict__ in, typename G::J *__restrict__ out, uint64_t n, uint64_t T) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    reduce_sum_thread<G>(in, out, n, T, t);
 }
 
 // y^2 == x^3 + a x + b for uncompressed inputs (compressed reads are on the curve by construction)
@@ -333,7 +379,8 @@ struct GroupOps {
     void (*scalar_mul)(hipStream_t, const uint8_t *in, int cin, void *scratch, uint64_t n, const uint32_t *table,
                        int check_input, int *err);
     void (*window_scalar_mul)(hipStream_t, const uint8_t *in, int cin, void *scratch, void *wtab, uint64_t n,
-                              const uint32_t *table, int check_input, const uint32_t *fixed_scalar, int *err);
+                              ScalarSource src, int check_input, int *err);
+    void (*reduce_sum)(hipStream_t, const void *in, void *out, uint64_t n, uint64_t T);
     void (*on_curve)(hipStream_t, const uint8_t *in, uint64_t n, int *err);
     void (*fixed_scalar_mul)(hipStream_t, const uint8_t *in, int cin, void *scratch, uint64_t n,
                              const uint32_t *scalar, int nbits, int *err);
@@ -378,10 +425,14 @@ struct Launch {
                            check_input, err);
     }
     static void window_scalar_mul(hipStream_t s, const uint8_t *in, int cin, void *scratch, void *wtab, uint64_t n,
-                                  const uint32_t *table, int check_input, const uint32_t *fixed_scalar, int *err) {
+                                  ScalarSource src, int check_input, int *err) {
         if (!n) return;
         hipLaunchKernelGGL(window_scalar_mul_kernel<G>, grid(n), dim3(256), 0, s, in, cin, (typename G::J *)scratch,
-                           (typename G::J *)wtab, n, table, check_input, fixed_scalar, err);
+                           (typename G::J *)wtab, n, src, check_input, err);
+    }
+    static void reduce_sum(hipStream_t s, const void *in, void *out, uint64_t n, uint64_t T) {
+        if (!T) return;
+        hipLaunchKernelGGL(reduce_sum_kernel<G>, grid(T), dim3(256), 0, s, (const typename G::J *)in, (typename G::J *)out, n, T);
     }
     static void on_curve(hipStream_t s, const uint8_t *in, uint64_t n, int *err) {
         if (!n) return;
@@ -419,6 +470,7 @@ struct Launch {
         o.scalar_mul = scalar_mul;
         o.window_scalar_mul = window_scalar_mul;
         o.on_curve = on_curve;
+        o.reduce_sum = reduce_sum;
         o.fixed_scalar_mul = fixed_scalar_mul;
         o.normalize = normalize;
         o.expect_infinity = expect_infinity;

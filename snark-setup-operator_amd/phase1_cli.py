@@ -240,6 +240,53 @@ def transform_pok_and_correctness(challenge_filename, challenge_hash_filename, c
     _lib.check(rc, eb)
 
 
+def dense_multiexp(curve, group, data: bytes, scalars, compressed_in=False, compressed_out=False, device=0) -> bytes:
+    """setup_utils::dense_multiexp: sum_i scalars[i] * P_i -> one serialized point."""
+    L = _lib.load_library()
+    c = curve_from_str(curve) if isinstance(curve, str) else int(curve)
+    nl = L.ptau_fr_limbs(c)
+    n = len(scalars)
+    flat = []
+    for s in scalars:
+        flat += [(s >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(nl)]
+    arr = (ctypes.c_uint64 * max(1, len(flat)))(*flat)
+    out = ctypes.create_string_buffer(L.ptau_point_size(c, group, int(compressed_out)))
+    eb = _lib.errbuf()
+    _lib.check(L.ptau_msm(c, group, data, int(compressed_in), n, arr, out, int(compressed_out), device, eb, len(eb)), eb)
+    return out.raw
+
+
+MASK64 = (1 << 64) - 1
+
+
+def _splitmix64(z):
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & MASK64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & MASK64
+    return z ^ (z >> 31)
+
+
+def power_pairs_coefficient(seed: bytes, idx: int, fr_bits: int) -> int:
+    """The coefficient rho_idx that ptau_power_pairs uses (documented PRF, kernels_impl.hpp::prf_word)."""
+    s0, s1 = int.from_bytes(seed[:8], "little"), int.from_bytes(seed[8:16], "little")
+    nl = (fr_bits + 31) // 32
+    v = 0
+    for j in range(nl):
+        z = _splitmix64((s0 + (idx * nl + j + 1) * 0x9E3779B97F4A7C15) & MASK64) ^ s1
+        v |= (_splitmix64(z) >> 32) << (32 * j)
+    return v & ((1 << (fr_bits - 1)) - 1)
+
+
+def power_pairs(curve, group, data: bytes, n, seed: bytes = None, index_base=0, compressed_in=False, device=0):
+    """setup_utils::power_pairs: (sum rho_i P_i, sum rho_i P_{i+1}) as two uncompressed points."""
+    L = _lib.load_library()
+    c = curve_from_str(curve) if isinstance(curve, str) else int(curve)
+    sz = L.ptau_point_size(c, group, 0)
+    a, b = ctypes.create_string_buffer(sz), ctypes.create_string_buffer(sz)
+    eb = _lib.errbuf()
+    _lib.check(L.ptau_power_pairs(c, group, data, int(compressed_in), n, seed, index_base, a, b, device, eb, len(eb)), eb)
+    return a.raw, b.raw
+
+
 def last_timing(device=0):
     t = _lib.ptau_timing()
     _lib.load_library().ptau_last_timing(device, ctypes.byref(t))

@@ -144,3 +144,44 @@ def test_contribute_verify_round_trip_2pow12(pkg, cref):
         G1 = Group(c, 1)
         n1 = p.g1_chunk_size
         assert nc[64:64 + n1 * 96] == cref.decompress(name, 1, bytes(resp[64:64 + n1 * 48]), n1, nthreads=8)
+
+
+@pytest.mark.parametrize("name,group,n", [("bls12_377", 1, 1000), ("bls12_377", 2, 200), ("bw6", 1, 150), ("bw6", 2, 150),
+                                          ("mnt4_753", 1, 100), ("mnt4_753", 2, 40), ("mnt6_753", 1, 100), ("mnt6_753", 2, 24)])
+def test_msm_and_power_pairs(name, group, n, pkg, cref):
+    """dense_multiexp with explicit scalars, and power_pairs with its documented coefficient generator,
+    both bit-exact against the oracle's serial sum of scalar multiplications."""
+    c = CURVES[name]
+    G = Group(c, group)
+    rng = random.Random(31 + group)
+    base = [G.mul(G.gen, rng.randrange(1, c.r)) for _ in range(5)]
+    pts = [base[i % 5] if i % 11 else None for i in range(n)]       # repeated points + some infinities
+    data = serde.write_batch(G, pts, False)
+    nl = cref.fr_limbs(name)
+    scalars = [rng.randrange(c.r) for _ in range(n)]
+    scalars[0], scalars[1] = 0, 1
+    exp = cref.msm(name, group, data, n, scalars, nl)
+    assert pkg.phase1_cli.dense_multiexp(name, group, data, scalars) == exp
+    # empty and single-element sums
+    assert pkg.phase1_cli.dense_multiexp(name, group, b"", []) == serde.write_point(G, None, False)
+    assert pkg.phase1_cli.dense_multiexp(name, group, data[:G.uncomp_size], [7]) == cref.msm(name, group, data[:G.uncomp_size], 1, [7], nl)
+    # power_pairs: same rho on the vector and on its shift by one
+    seed = bytes(range(16))
+    rho = [pkg.phase1_cli.power_pairs_coefficient(seed, 1000 + i, c.r.bit_length()) for i in range(n - 1)]
+    a, b = pkg.phase1_cli.power_pairs(name, group, data, n, seed=seed, index_base=1000)
+    assert a == cref.msm(name, group, data, n - 1, rho, nl)
+    assert b == cref.msm(name, group, data[G.uncomp_size:], n - 1, rho, nl)
+
+
+def test_power_pairs_ratio_property_full_size(pkg):
+    """Size-independent property on a 2^18-point geometric vector v_i = s^i G: power_pairs gives (A, B) with
+    B = s*A — the relation check_same_ratio tests with pairings — here checked by one more GPU scalar-mul."""
+    name, n = "bls12_377", 1 << 18
+    c = CURVES[name]
+    G = Group(c, 1)
+    s = 0x1234567890abcdef1234567890abcdef % c.r
+    gen = serde.write_point(G, G.gen, False) * n
+    v = pkg.phase1_cli.apply_powers(name, 1, gen, n, 0, s, None, False, False)
+    a, b = pkg.phase1_cli.power_pairs(name, 1, v, n)        # fresh OS entropy
+    sa = pkg.phase1_cli.apply_powers(name, 1, a, 1, 1, s, None, False, False)    # s^1 * A
+    assert sa == b and a != serde.write_point(G, None, False)
