@@ -174,6 +174,13 @@ int ptau_msm(int curve, int group, const uint8_t *in, int compressed_in, uint64_
 int ptau_power_pairs(int curve, int group, const uint8_t *in, int compressed_in, uint64_t n, const uint8_t seed[16],
                      uint64_t index_base, uint8_t *out_a, uint8_t *out_b, int device, char *err, size_t err_len);
 
+/* setup_utils::check_same_ratio((a, b), (c, d)) — e(a, d) == e(b, c) — reference call sites
+ * src/bin/verify_transcript.rs:812-822, src/bin/control.rs:587-591 (inside transform_ratios / verification).
+ * a, b: G1 points, c, d: G2 points, all UNCOMPRESSED.  The O(1) pairing tail runs on the host CPU.
+ * Returns PTAU_OK when the ratios agree, PTAU_E_INVALID_RATIO when they do not. */
+int ptau_check_same_ratio(int curve, const uint8_t *g1_a, const uint8_t *g1_b, const uint8_t *g2_c,
+                          const uint8_t *g2_d, char *err, size_t err_len);
+
 /* Timings of the most recent compute call on `device`. */
 int ptau_last_timing(int device, ptau_timing *out);
 

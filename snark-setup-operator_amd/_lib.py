@@ -19,7 +19,7 @@ DECLARED_SYMBOLS = [
     "ptau_strerror", "ptau_device_count", "ptau_device_info", "ptau_params_sizes", "ptau_point_size",
     "ptau_fr_limbs", "ptau_blake2b512", "ptau_apply_powers", "ptau_apply_powers_dev", "ptau_phase1_computation",
     "ptau_contribute_file", "ptau_decompress", "ptau_last_timing", "ptau_subgroup_check", "ptau_verify_chunk",
-    "ptau_transform_pok_and_correctness_file", "ptau_msm", "ptau_power_pairs",
+    "ptau_transform_pok_and_correctness_file", "ptau_msm", "ptau_power_pairs", "ptau_check_same_ratio",
 ]
 
 
@@ -74,6 +74,7 @@ def load_library():
     L.ptau_last_timing.argtypes = [i, ctypes.POINTER(ptau_timing)]
     L.ptau_msm.argtypes = [i, i, u8p, i, u64, u64p, u8p, i, i, cp, sz]
     L.ptau_power_pairs.argtypes = [i, i, u8p, i, u64, u8p, u64, u8p, u8p, i, cp, sz]
+    L.ptau_check_same_ratio.argtypes = [i, u8p, u8p, u8p, u8p, cp, sz]
     L.ptau_subgroup_check.argtypes = [i, i, u8p, i, u64, i, cp, sz]
     L.ptau_verify_chunk.argtypes = [ctypes.POINTER(ptau_params), u8p, sz, u8p, sz, u8p, sz, i, i, i, i, i, cp, sz]
     L.ptau_transform_pok_and_correctness_file.argtypes = [ctypes.POINTER(ptau_params), cp, cp, i, cp, cp, i, cp, cp, i, i, i, cp, sz]

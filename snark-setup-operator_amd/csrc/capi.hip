@@ -22,6 +22,7 @@
 
 #include "../../include/ptau.h"
 #include "kernels_impl.hpp"
+#include "pairing_host.hpp"
 
 namespace {
 
@@ -827,6 +828,24 @@ int ptau_power_pairs(int curve, int group, const uint8_t *in, int compressed_in,
     // (sum rho_i P_i, sum rho_i P_{i+1}), i in [0, n-1): the same coefficients on the vector and on its shift
     if ((rc = run_msm_dev(c, ops, (const uint8_t *)c->d_in, compressed_in, n - 1, src, out_a, 0, err))) return rc;
     return run_msm_dev(c, ops, (const uint8_t *)c->d_in + isz, compressed_in, n - 1, src, out_b, 0, err);
+}
+
+int ptau_check_same_ratio(int curve, const uint8_t *g1_a, const uint8_t *g1_b, const uint8_t *g2_c, const uint8_t *g2_d,
+                          char *errbuf, size_t err_len) {
+    using namespace ptau;
+    Err err{errbuf, err_len};
+    if (!g1_a || !g1_b || !g2_c || !g2_d) return err.fail(PTAU_E_ARG, "null pointer argument");
+    int r;
+    switch (curve) {
+    case PTAU_CURVE_BLS12_377: r = TatePairing<BlsFq, BlsFr, BlsG1Cfg, BlsG2Cfg, BlsPairingCfg>::check_same_ratio(g1_a, g1_b, g2_c, g2_d); break;
+    case PTAU_CURVE_BW6_761: r = TatePairing<Bw6Fq, Bw6Fr, Bw6G1Cfg, Bw6G2Cfg, Bw6PairingCfg>::check_same_ratio(g1_a, g1_b, g2_c, g2_d); break;
+    case PTAU_CURVE_MNT4_753: r = TatePairing<Mnt4Fq, Mnt4Fr, Mnt4G1Cfg, Mnt4G2Cfg, Mnt4PairingCfg>::check_same_ratio(g1_a, g1_b, g2_c, g2_d); break;
+    case PTAU_CURVE_MNT6_753: r = TatePairing<Mnt6Fq, Mnt6Fr, Mnt6G1Cfg, Mnt6G2Cfg, Mnt6PairingCfg>::check_same_ratio(g1_a, g1_b, g2_c, g2_d); break;
+    default: return err.fail(PTAU_E_ARG, "unknown curve id %d", curve);
+    }
+    if (r < 0) return err.fail(PTAU_E_POINT, "non-canonical point in a ratio pair");
+    if (r == 0) return err.fail(PTAU_E_INVALID_RATIO, "the two pairs do not have the same ratio");
+    return PTAU_OK;
 }
 
 }  // extern "C"

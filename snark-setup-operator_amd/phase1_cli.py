@@ -287,6 +287,18 @@ def power_pairs(curve, group, data: bytes, n, seed: bytes = None, index_base=0, 
     return a.raw, b.raw
 
 
+def check_same_ratio(curve, g1_pair, g2_pair) -> bool:
+    """setup_utils::check_same_ratio((a, b), (c, d)): e(a, d) == e(b, c).  Points are uncompressed bytes."""
+    L = _lib.load_library()
+    c = curve_from_str(curve) if isinstance(curve, str) else int(curve)
+    eb = _lib.errbuf()
+    rc = L.ptau_check_same_ratio(c, g1_pair[0], g1_pair[1], g2_pair[0], g2_pair[1], eb, len(eb))
+    if rc == -6:
+        return False
+    _lib.check(rc, eb)
+    return True
+
+
 def last_timing(device=0):
     t = _lib.ptau_timing()
     _lib.load_library().ptau_last_timing(device, ctypes.byref(t))
