@@ -147,11 +147,16 @@ int ptau_subgroup_check(int curve, int group, const uint8_t *in, int compressed_
  *   - response[0..64) must equal BLAKE2b(challenge)             -> PTAU_E_HASH_CHAIN
  *   - every response element: canonical, on the curve, non-zero per check_output, in the prime-order
  *     subgroup unless subgroup_check_mode == PTAU_SUBGROUP_NO      -> PTAU_E_POINT / _AT_INFINITY / _NOT_IN_SUBGROUP
+ *   - ratio_check (contribute.rs:146-147,954,984): check_power_ratios of every vector — power_pairs on the GPU,
+ *     check_same_ratio on the host — against (tauG2[j], tauG2[j+1]) / (tauG1[j], tauG1[j+1]) of this chunk;
+ *     a chunk without tauG2 elements (start >= 2^power) needs tau_g2_check = two UNCOMPRESSED G2 points
+ *     (tauG2[0], tauG2[1]) of the same contribution, else NULL          -> PTAU_E_INVALID_RATIO
  *   - new_challenge = BLAKE2b(response) | decompressed elements (accumulator_size bytes).
- * The proof-of-knowledge and ratio pairing checks are the O(1) tail (ptau_check_same_ratio). */
+ * The proof-of-knowledge checks on the public key are ptau_verify_pok. */
 int ptau_verify_chunk(const ptau_params *p, const uint8_t *challenge, size_t challenge_len, const uint8_t *response,
                       size_t response_len, uint8_t *new_challenge, size_t new_challenge_len, int check_input,
-                      int check_output, int subgroup_check_mode, int ratio_check, int device, char *err, size_t err_len);
+                      int check_output, int subgroup_check_mode, int ratio_check, const uint8_t *tau_g2_check,
+                      int device, char *err, size_t err_len);
 
 /* phase1_cli::transform_pok_and_correctness, file level (src/bin/contribute.rs:968-986): writes the three
  * 64-byte `.hash` side files and creates new_challenge_path (create_new semantics). */
@@ -159,7 +164,8 @@ int ptau_transform_pok_and_correctness_file(const ptau_params *p, const char *ch
                                             const char *challenge_hash_path, int check_input, const char *response_path,
                                             const char *response_hash_path, int check_output,
                                             const char *new_challenge_path, const char *new_challenge_hash_path,
-                                            int subgroup_check_mode, int ratio_check, int device, char *err, size_t err_len);
+                                            int subgroup_check_mode, int ratio_check, const uint8_t *tau_g2_check,
+                                            int device, char *err, size_t err_len);
 
 /* setup_utils::dense_multiexp — sum_i scalars[i] * in[i] -> one serialized point (host buffers; scalars are
  * n x ptau_fr_limbs(curve) canonical limbs).  Used inside merge_pairs / power_pairs. */

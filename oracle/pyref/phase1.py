@@ -228,3 +228,36 @@ def aggregation(chunk_params, responses, full: Params) -> bytes:
     out = bytes(HASH_SIZE) + vecs["tau_g1"] + vecs["tau_g2"] + vecs["alpha_g1"] + vecs["beta_g1"] + vecs["beta_g2"]
     assert len(out) == full.accumulator_size
     return out
+
+
+def power_pairs(G: Group, pts, rng):
+    """setup_utils::power_pairs / merge_pairs (SURVEY §8 a13): random rho_i, (sum rho_i v_i, sum rho_i v_{i+1})."""
+    a = b = None
+    for i in range(len(pts) - 1):
+        rho = rng.randrange(1, G.r)
+        a = G.add(a, G.mul(pts[i], rho))
+        b = G.add(b, G.mul(pts[i + 1], rho))
+    return a, b
+
+
+def verify_chunk_ratios(p: Params, response: bytes, tau_g2_check=None, rng=None) -> bool:
+    """check_power_ratios part of Phase1::verification (contribute.rs:968-986 with ratio_check): every vector
+    of the response must be geometric with the ratio of (tauG2[j], tauG2[j+1]) resp. (tauG1[j], tauG1[j+1])."""
+    import random
+    from .pairing import Pairing
+    rng = rng or random.Random()
+    Pg = Pairing(p.curve)
+    G1, G2 = Pg.G1, Pg.G2
+    vecs = {}
+    for (name, grp, off, cnt) in p.layout(True)[0]:
+        G = G1 if grp == 1 else G2
+        vecs[name] = serde.read_batch(G, response[off:off + cnt * G.comp_size], True)
+    g2_pair = tuple(vecs["tau_g2"][:2]) if len(vecs["tau_g2"]) >= 2 else tau_g2_check
+    assert g2_pair is not None
+    for name in ("tau_g1", "alpha_g1", "beta_g1"):
+        if len(vecs[name]) >= 2 and not Pg.check_same_ratio(power_pairs(G1, vecs[name], rng), g2_pair):
+            return False
+    if len(vecs["tau_g2"]) >= 2 and len(vecs["tau_g1"]) >= 2:
+        if not Pg.check_same_ratio(tuple(vecs["tau_g1"][:2]), power_pairs(G2, vecs["tau_g2"], rng)):
+            return False
+    return True

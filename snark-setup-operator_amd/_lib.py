@@ -76,8 +76,8 @@ def load_library():
     L.ptau_power_pairs.argtypes = [i, i, u8p, i, u64, u8p, u64, u8p, u8p, i, cp, sz]
     L.ptau_check_same_ratio.argtypes = [i, u8p, u8p, u8p, u8p, cp, sz]
     L.ptau_subgroup_check.argtypes = [i, i, u8p, i, u64, i, cp, sz]
-    L.ptau_verify_chunk.argtypes = [ctypes.POINTER(ptau_params), u8p, sz, u8p, sz, u8p, sz, i, i, i, i, i, cp, sz]
-    L.ptau_transform_pok_and_correctness_file.argtypes = [ctypes.POINTER(ptau_params), cp, cp, i, cp, cp, i, cp, cp, i, i, i, cp, sz]
+    L.ptau_verify_chunk.argtypes = [ctypes.POINTER(ptau_params), u8p, sz, u8p, sz, u8p, sz, i, i, i, i, u8p, i, cp, sz]
+    L.ptau_transform_pok_and_correctness_file.argtypes = [ctypes.POINTER(ptau_params), cp, cp, i, cp, cp, i, cp, cp, i, i, u8p, i, cp, sz]
     _lib = L
     return L
 

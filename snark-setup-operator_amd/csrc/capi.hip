@@ -83,6 +83,7 @@ struct DeviceCtx {
     uint32_t *d_table = nullptr;   // scalar table (65 entries x 24 limbs max)
     int *d_err = nullptr;
     void *d_in = nullptr, *d_out = nullptr;   // staging for the host-buffer entry points
+    void *d_small = nullptr;                  // single-point results (MSM)
     size_t in_cap = 0, out_cap = 0;
     ptau_timing timing = {};
 };
@@ -101,6 +102,7 @@ int ensure_ctx(int device, DeviceCtx *&c, const Err &err) {
         for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
         HIP_TRY(hipMalloc(&c->d_table, sizeof(uint32_t) * (1 + ptau::SCALAR_TABLE_ENTRIES) * 24));
         HIP_TRY(hipMalloc(&c->d_err, sizeof(int)));
+        HIP_TRY(hipMalloc(&c->d_small, 4096));
         c->ready = true;
     }
     return PTAU_OK;
@@ -197,6 +199,61 @@ int run_apply_powers_host(DeviceCtx *c, const GroupOps *ops, const uint8_t *in, 
     return PTAU_OK;
 }
 
+// sum_i k_i * P_i over n device-resident points -> ONE serialized affine point in host memory.
+// Round-1 form: n windowed scalar multiplications (the K1 kernel) followed by a tree of Jacobian sums;
+// a bucket (Pippenger) accumulation is the planned replacement.  Caller holds the device mutex.
+int run_msm_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, int cin, uint64_t n, ptau::ScalarSource src,
+                uint8_t *out_host, int cout, const Err &err) {
+    const int isz = cin ? ops->comp : ops->uncomp, osz = cout ? ops->comp : ops->uncomp;
+    const uint64_t launch_cap =
+        std::max<uint64_t>(256, std::min(MAX_LAUNCH_POINTS, MAX_WINDOW_TABLE_BYTES / (ptau::WINDOW_ENTRIES * ops->jac_bytes)));
+    int rc;
+    const uint64_t nlaunch = n ? (n + launch_cap - 1) / launch_cap : 1;
+    // partial sums: one Jacobian per launch, kept at the tail of the scratch area
+    if ((rc = grow(c->scratch, c->scratch_cap, (std::min(n, launch_cap) + 4096 + nlaunch + 8) * ops->jac_bytes, err))) return rc;
+    if ((rc = grow(c->pre, c->pre_cap, 16 * ops->fe_bytes, err))) return rc;
+    uint8_t *S = (uint8_t *)c->scratch;
+    const uint64_t cap = std::min(n, launch_cap);
+    uint8_t *level = S + cap * ops->jac_bytes;                       // 4096 partials
+    uint8_t *totals = level + 4096 * ops->jac_bytes;                 // nlaunch partial totals (+ final)
+    HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
+    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    uint64_t li = 0;
+    for (uint64_t off = 0; off < n; off += launch_cap, li++) {
+        const uint64_t m = std::min(launch_cap, n - off);
+        if ((rc = grow(c->wtab, c->wtab_cap, m * ptau::WINDOW_ENTRIES * ops->jac_bytes, err))) return rc;
+        ptau::ScalarSource s2 = src;
+        if (s2.mode == ptau::SCALAR_ARRAY) s2.ptr += off * ops->fr_limbs32;
+        s2.index_base += off;
+        ops->window_scalar_mul(c->stream, d_in + off * isz, cin, S, c->wtab, m, s2, 0, c->d_err);
+        // tree: m -> min(m,4096)·.. -> 64 -> 1
+        const uint64_t t1 = std::min<uint64_t>(4096, (m + 15) / 16);
+        ops->reduce_sum(c->stream, S, level, m, t1);
+        const uint64_t t2 = std::min<uint64_t>(64, t1);
+        ops->reduce_sum(c->stream, level, S, t1, t2);               // reuse the head of S for level 2
+        ops->reduce_sum(c->stream, S, totals + li * ops->jac_bytes, t2, 1);
+    }
+    if (n == 0) {
+        ops->reduce_sum(c->stream, S, totals, 0, 1);                // empty sum = infinity
+        li = 1;
+    }
+    ops->reduce_sum(c->stream, totals, totals + nlaunch * ops->jac_bytes, li, 1);
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    // normalise + serialise the single result
+    ops->normalize(c->stream, totals + nlaunch * ops->jac_bytes, c->pre, (uint8_t *)c->d_small, cout, 1, 1, 0, c->d_err);
+    int bits = 0;
+    HIP_TRY(hipMemcpyAsync(&bits, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(out_host, c->d_small, osz, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    c->timing.kernel_ms += ms;
+    c->timing.scalar_mul_ms += ms;
+    c->timing.points += n;
+    return errbits_to_code(bits, err);
+}
+
 bool cofactor_is_one(int curve, int group) {
     return group == PTAU_G1 && (curve == PTAU_CURVE_MNT4_753 || curve == PTAU_CURVE_MNT6_753);
 }
@@ -241,7 +298,8 @@ int run_subgroup_check_dev(DeviceCtx *c, int curve, int group, const GroupOps *o
 // One response vector of a chunk: compressed host bytes -> (sqrt) -> non-zero / subgroup checks -> uncompressed
 // host bytes of the next challenge.  Caller holds the device mutex.
 int run_verify_vector(DeviceCtx *c, int curve, int group, const GroupOps *ops, const uint8_t *in, uint8_t *out, uint64_t n,
-                      int check_output, int subgroup_check_mode, const Err &err) {
+                      int check_output, int subgroup_check_mode, const uint64_t *ratio_seed, uint64_t index_base,
+                      uint8_t *pair_a, uint8_t *pair_b, const Err &err) {
     if (!n) return PTAU_OK;
     int rc;
     if ((rc = grow(c->d_in, c->in_cap, n * ops->comp, err))) return rc;
@@ -267,6 +325,11 @@ int run_verify_vector(DeviceCtx *c, int curve, int group, const GroupOps *ops, c
     const bool want_subgroup = subgroup_check_mode != PTAU_SUBGROUP_NO || check_output == PTAU_CHECK_ONLY_IN_GROUP ||
                                check_output == PTAU_CHECK_FULL;
     if (want_subgroup && (rc = run_subgroup_check_dev(c, curve, group, ops, (const uint8_t *)c->d_out, 0, n, err))) return rc;
+    if (ratio_seed && n >= 2) {   // power_pairs on the vector while it is still resident in HBM
+        const ptau::ScalarSource src{ptau::SCALAR_PRF, nullptr, ratio_seed[0], ratio_seed[1], index_base};
+        if ((rc = run_msm_dev(c, ops, (const uint8_t *)c->d_out, 0, n - 1, src, pair_a, 0, err))) return rc;
+        if ((rc = run_msm_dev(c, ops, (const uint8_t *)c->d_out + ops->uncomp, 0, n - 1, src, pair_b, 0, err))) return rc;
+    }
     HIP_TRY(hipEventRecord(c->ev[3], c->stream));
     HIP_TRY(hipMemcpyAsync(out, c->d_out, n * ops->uncomp, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipEventRecord(c->ev[4], c->stream));
@@ -274,62 +337,6 @@ int run_verify_vector(DeviceCtx *c, int curve, int group, const GroupOps *ops, c
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
     c->timing.d2h_ms += ms;
     return PTAU_OK;
-}
-
-// sum_i k_i * P_i over n device-resident points -> ONE serialized affine point in host memory.
-// Round-1 form: n windowed scalar multiplications (the K1 kernel) followed by a tree of Jacobian sums;
-// a bucket (Pippenger) accumulation is the planned replacement.  Caller holds the device mutex.
-int run_msm_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, int cin, uint64_t n, ptau::ScalarSource src,
-                uint8_t *out_host, int cout, const Err &err) {
-    const int isz = cin ? ops->comp : ops->uncomp, osz = cout ? ops->comp : ops->uncomp;
-    const uint64_t launch_cap =
-        std::max<uint64_t>(256, std::min(MAX_LAUNCH_POINTS, MAX_WINDOW_TABLE_BYTES / (ptau::WINDOW_ENTRIES * ops->jac_bytes)));
-    int rc;
-    const uint64_t nlaunch = n ? (n + launch_cap - 1) / launch_cap : 1;
-    // partial sums: one Jacobian per launch, kept at the tail of the scratch area
-    if ((rc = grow(c->scratch, c->scratch_cap, (std::min(n, launch_cap) + 4096 + nlaunch + 8) * ops->jac_bytes, err))) return rc;
-    if ((rc = grow(c->pre, c->pre_cap, 16 * ops->fe_bytes, err))) return rc;
-    uint8_t *S = (uint8_t *)c->scratch;
-    const uint64_t cap = std::min(n, launch_cap);
-    uint8_t *level = S + cap * ops->jac_bytes;                       // 4096 partials
-    uint8_t *totals = level + 4096 * ops->jac_bytes;                 // nlaunch partial totals (+ final)
-    HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
-    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-    uint64_t li = 0;
-    for (uint64_t off = 0; off < n; off += launch_cap, li++) {
-        const uint64_t m = std::min(launch_cap, n - off);
-        if ((rc = grow(c->wtab, c->wtab_cap, m * ptau::WINDOW_ENTRIES * ops->jac_bytes, err))) return rc;
-        ptau::ScalarSource s2 = src;
-        if (s2.mode == ptau::SCALAR_ARRAY) s2.ptr += off * ops->fr_limbs32;
-        s2.index_base += off;
-        ops->window_scalar_mul(c->stream, d_in + off * isz, cin, S, c->wtab, m, s2, 0, c->d_err);
-        // tree: m -> min(m,4096)·.. -> 64 -> 1
-        const uint64_t t1 = std::min<uint64_t>(4096, (m + 15) / 16);
-        ops->reduce_sum(c->stream, S, level, m, t1);
-        const uint64_t t2 = std::min<uint64_t>(64, t1);
-        ops->reduce_sum(c->stream, level, S, t1, t2);               // reuse the head of S for level 2
-        ops->reduce_sum(c->stream, S, totals + li * ops->jac_bytes, t2, 1);
-    }
-    if (n == 0) {
-        ops->reduce_sum(c->stream, S, totals, 0, 1);                // empty sum = infinity
-        li = 1;
-    }
-    ops->reduce_sum(c->stream, totals, totals + nlaunch * ops->jac_bytes, li, 1);
-    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-    // normalise + serialise the single result
-    if ((rc = grow(c->d_out, c->out_cap, std::max<size_t>(c->out_cap, 2 * ops->uncomp), err))) return rc;
-    ops->normalize(c->stream, totals + nlaunch * ops->jac_bytes, c->pre, (uint8_t *)c->d_out, cout, 1, 1, 0, c->d_err);
-    int bits = 0;
-    HIP_TRY(hipMemcpyAsync(&bits, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(out_host, c->d_out, osz, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipGetLastError());
-    float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
-    c->timing.kernel_ms += ms;
-    c->timing.scalar_mul_ms += ms;
-    c->timing.points += n;
-    return errbits_to_code(bits, err);
 }
 
 int check_params(const ptau_params *p, const Err &err) {
@@ -696,7 +703,8 @@ int ptau_subgroup_check(int curve, int group, const uint8_t *in, int compressed_
 
 int ptau_verify_chunk(const ptau_params *p, const uint8_t *challenge, size_t challenge_len, const uint8_t *response,
                       size_t response_len, uint8_t *new_challenge, size_t new_challenge_len, int check_input,
-                      int check_output, int subgroup_check_mode, int ratio_check, int device, char *errbuf, size_t err_len) {
+                      int check_output, int subgroup_check_mode, int ratio_check, const uint8_t *tau_g2_check,
+                      int device, char *errbuf, size_t err_len) {
     Err err{errbuf, err_len};
     int rc = check_params(p, err);
     if (rc) return rc;
@@ -708,8 +716,6 @@ int ptau_verify_chunk(const ptau_params *p, const uint8_t *challenge, size_t cha
     if (response_len != sz.contribution_size)
         return err.fail(PTAU_E_LEN, "response is %zu bytes, parameters require %llu", response_len,
                         (unsigned long long)sz.contribution_size);
-    if (ratio_check)
-        return err.fail(PTAU_E_UNSUPPORTED, "ratio_check needs the pairing tail (ptau_check_same_ratio): not built yet");
     // hash chain: response[0..64) must be BLAKE2b(challenge)
     uint8_t digest[64];
     ptau_blake2b512(challenge, challenge_len, digest);
@@ -725,11 +731,51 @@ int ptau_verify_chunk(const ptau_params *p, const uint8_t *challenge, size_t cha
     const uint64_t n1 = sz.g1_chunk_size, n2 = sz.other_chunk_size;
     const uint8_t *pi = response + 64;
     uint8_t *po = new_challenge + 64;
-    struct { const GroupOps *ops; int group; uint64_t n; } vec[5] = {{g1, 1, n1}, {g2, 2, n2}, {g1, 1, n2}, {g1, 1, n2}, {g2, 2, 1}};
-    for (auto &v : vec) {
-        if ((rc = run_verify_vector(c, p->curve, v.group, v.ops, pi, po, v.n, check_output, subgroup_check_mode, err))) return rc;
+    struct { const GroupOps *ops; int group; uint64_t n; const char *name; } vec[5] = {
+        {g1, 1, n1, "tau_g1"}, {g2, 2, n2, "tau_g2"}, {g1, 1, n2, "alpha_g1"}, {g1, 1, n2, "beta_g1"}, {g2, 2, 1, "beta_g2"}};
+    uint64_t seed[2] = {0, 0};
+    if (ratio_check) {   // fresh secret for the random linear combinations of this verification
+        FILE *f = fopen("/dev/urandom", "rb");
+        if (!f || fread(seed, 1, 16, f) != 16) {
+            if (f) fclose(f);
+            return err.fail(PTAU_E_IO, "cannot read /dev/urandom for the random linear combination");
+        }
+        fclose(f);
+    }
+    std::vector<uint8_t> pairs(5 * 2 * (size_t)g2->uncomp);   // (A, B) per vector
+    uint8_t *vec_out[5];
+    for (int k = 0; k < 5; k++) {
+        auto &v = vec[k];
+        vec_out[k] = po;
+        uint8_t *pa = pairs.data() + (size_t)k * 2 * g2->uncomp, *pb = pa + g2->uncomp;
+        if ((rc = run_verify_vector(c, p->curve, v.group, v.ops, pi, po, v.n, check_output, subgroup_check_mode,
+                                    ratio_check ? seed : nullptr, sz.start, pa, pb, err)))
+            return rc;
         pi += v.n * v.ops->comp;
         po += v.n * v.ops->uncomp;
+    }
+    if (ratio_check) {
+        // check_power_ratios: consecutive elements of every vector differ by the SAME factor tau, i.e.
+        // (sum rho_i v_i, sum rho_i v_{i+1}) has the ratio of (tauG2[j], tauG2[j+1]) resp. (tauG1[j], tauG1[j+1]).
+        const uint8_t *g2_pair = nullptr, *g1_pair = n1 >= 2 ? vec_out[0] : nullptr;
+        if (n2 >= 2) g2_pair = vec_out[1];
+        else if (tau_g2_check) g2_pair = tau_g2_check;
+        if (!g2_pair)
+            return err.fail(PTAU_E_ARG, "ratio_check on a chunk without tauG2 elements needs tau_g2_check (tauG2[0], tauG2[1])");
+        const int g1_vecs[3] = {0, 2, 3};
+        for (int k : g1_vecs) {
+            if (vec[k].n < 2) continue;
+            const uint8_t *pa = pairs.data() + (size_t)k * 2 * g2->uncomp, *pb = pa + g2->uncomp;
+            rc = ptau_check_same_ratio(p->curve, pa, pb, g2_pair, g2_pair + g2->uncomp, errbuf, err_len);
+            if (rc == PTAU_E_INVALID_RATIO) return err.fail(rc, "power ratio check failed for %s", vec[k].name);
+            if (rc) return rc;
+        }
+        if (n2 >= 2 && g1_pair) {
+            const uint8_t *pa = pairs.data() + (size_t)1 * 2 * g2->uncomp, *pb = pa + g2->uncomp;
+            rc = ptau_check_same_ratio(p->curve, g1_pair, g1_pair + g1->uncomp, pa, pb, errbuf, err_len);
+            if (rc == PTAU_E_INVALID_RATIO) return err.fail(rc, "power ratio check failed for tau_g2");
+            if (rc) return rc;
+        }
     }
     // new_challenge = BLAKE2b(response) | decompressed elements
     ptau_blake2b512(response, response_len, new_challenge);
@@ -740,7 +786,7 @@ int ptau_transform_pok_and_correctness_file(const ptau_params *p, const char *ch
                                             int check_input, const char *response_path, const char *response_hash_path,
                                             int check_output, const char *new_challenge_path,
                                             const char *new_challenge_hash_path, int subgroup_check_mode, int ratio_check,
-                                            int device, char *errbuf, size_t err_len) {
+                                            const uint8_t *tau_g2_check, int device, char *errbuf, size_t err_len) {
     Err err{errbuf, err_len};
     int rc = check_params(p, err);
     if (rc) return rc;
@@ -762,7 +808,8 @@ int ptau_transform_pok_and_correctness_file(const ptau_params *p, const char *ch
     if ((rc = write_small_file(response_hash_path, digest, 64, err))) return rc;
     if ((rc = nc.create_new(new_challenge_path, sz.accumulator_size, err))) return rc;
     if ((rc = ptau_verify_chunk(p, (const uint8_t *)ch.p, ch.len, (const uint8_t *)resp.p, resp.len, (uint8_t *)nc.p, nc.len,
-                                check_input, check_output, subgroup_check_mode, ratio_check, device, errbuf, err_len)))
+                                check_input, check_output, subgroup_check_mode, ratio_check, tau_g2_check, device, errbuf,
+                                err_len)))
         return rc;
     ptau_blake2b512((const uint8_t *)nc.p, nc.len, digest);
     if (msync(nc.p, nc.len, MS_SYNC)) return err.fail(PTAU_E_IO, "msync failed: %s", strerror(errno));

@@ -213,14 +213,15 @@ def subgroup_check(curve, group, data: bytes, n, compressed_in=False, device=0) 
 
 def verification_and_decompress(challenge: bytes, response: bytes, parameters: Phase1Parameters,
                                 check_input=CheckForCorrectness.No, check_output=CheckForCorrectness.OnlyNonZero,
-                                subgroup_check_mode=SubgroupCheckMode.Auto, ratio_check=False, device=0) -> bytes:
+                                subgroup_check_mode=SubgroupCheckMode.Auto, ratio_check=False, tau_g2_check: bytes = None,
+                                device=0) -> bytes:
     """Element part of Phase1::verification + Phase1::decompress on in-memory buffers; returns new_challenge."""
     L = _lib.load_library()
     out = ctypes.create_string_buffer(parameters.accumulator_size)
     eb = _lib.errbuf()
     rc = L.ptau_verify_chunk(ctypes.byref(parameters._c()), challenge, len(challenge), response, len(response), out, len(out),
-                             int(check_input), int(check_output), int(subgroup_check_mode), int(bool(ratio_check)), device,
-                             eb, len(eb))
+                             int(check_input), int(check_output), int(subgroup_check_mode), int(bool(ratio_check)),
+                             tau_g2_check, device, eb, len(eb))
     _lib.check(rc, eb)
     return out.raw
 
@@ -228,7 +229,7 @@ def verification_and_decompress(challenge: bytes, response: bytes, parameters: P
 def transform_pok_and_correctness(challenge_filename, challenge_hash_filename, check_input_correctness, response_filename,
                                   response_hash_filename, check_output_correctness, new_challenge_filename,
                                   new_challenge_hash_filename, subgroup_check_mode, ratio_check,
-                                  parameters: Phase1Parameters, device: int = 0):
+                                  parameters: Phase1Parameters, tau_g2_check: bytes = None, device: int = 0):
     """phase1_cli::transform_pok_and_correctness (contribute.rs:968-986), same argument order."""
     L = _lib.load_library()
     eb = _lib.errbuf()
@@ -236,7 +237,7 @@ def transform_pok_and_correctness(challenge_filename, challenge_hash_filename, c
         ctypes.byref(parameters._c()), os.fsencode(challenge_filename), os.fsencode(challenge_hash_filename),
         int(check_input_correctness), os.fsencode(response_filename), os.fsencode(response_hash_filename),
         int(check_output_correctness), os.fsencode(new_challenge_filename), os.fsencode(new_challenge_hash_filename),
-        int(subgroup_check_mode), int(bool(ratio_check)), device, eb, len(eb))
+        int(subgroup_check_mode), int(bool(ratio_check)), tau_g2_check, device, eb, len(eb))
     _lib.check(rc, eb)
 
 

@@ -185,3 +185,50 @@ def test_power_pairs_ratio_property_full_size(pkg):
     a, b = pkg.phase1_cli.power_pairs(name, 1, v, n)        # fresh OS entropy
     sa = pkg.phase1_cli.apply_powers(name, 1, a, 1, 1, s, None, False, False)    # s^1 * A
     assert sa == b and a != serde.write_point(G, None, False)
+
+
+@pytest.mark.parametrize("name", CURVE_NAMES)
+def test_verify_with_ratio_check(name, pkg, golden):
+    """ratio_check = true (the operator's default, contribute.rs:146-147): honest chunks pass, a response whose
+    elements are valid subgroup points but NOT a geometric sequence is rejected with PTAU_E_INVALID_RATIO.
+    The boolean outcome matches the oracle's own check_power_ratios (independent random coefficients)."""
+    doc = golden[name]
+    c = CURVES[name]
+    G1, G2 = Group(c, 1), Group(c, 2)
+    ch0, ch1 = doc["chunks"]
+    prm0, prm1 = _params(pkg, name, doc, 0), _params(pkg, name, doc, 1)
+    p0 = P.Params(c, P.CHUNKED, 0, doc["chunk_size"], doc["power"], doc["batch_size"])
+    p1 = P.Params(c, P.CHUNKED, 1, doc["chunk_size"], doc["power"], doc["batch_size"])
+    chal0, resp0 = bytes.fromhex(ch0["challenge"]), bytes.fromhex(ch0["response"])
+    nc0 = pkg.phase1_cli.verification_and_decompress(chal0, resp0, prm0, ratio_check=True)
+    assert pkg.calculate_hash(nc0).hex() == ch0["new_challenge_hash"]
+    assert P.verify_chunk_ratios(p0, resp0, rng=random.Random(1))
+    # tauG1-only chunk: needs (tauG2[0], tauG2[1]) of the same contribution
+    off_g2 = {nm: o for (nm, g, o, cnt) in p0.layout(False)[0]}["tau_g2"]
+    tau_g2_check = nc0[off_g2:off_g2 + 2 * G2.uncomp_size]
+    chal1, resp1 = bytes.fromhex(ch1["challenge"]), bytes.fromhex(ch1["response"])
+    with pytest.raises(pkg.PtauError) as e:
+        pkg.phase1_cli.verification_and_decompress(chal1, resp1, prm1, ratio_check=True)
+    assert e.value.code == -1
+    nc1 = pkg.phase1_cli.verification_and_decompress(chal1, resp1, prm1, ratio_check=True, tau_g2_check=tau_g2_check)
+    assert pkg.calculate_hash(nc1).hex() == ch1["new_challenge_hash"]
+    assert P.verify_chunk_ratios(p1, resp1, tau_g2_check=tuple(serde.read_batch(G2, tau_g2_check, False)), rng=random.Random(2))
+    # tamper: swap two tauG1 elements (still in the subgroup, no longer geometric)
+    bad = bytearray(resp0)
+    o = 64
+    a, b = bad[o + G1.comp_size:o + 2 * G1.comp_size], bad[o + 2 * G1.comp_size:o + 3 * G1.comp_size]
+    bad[o + G1.comp_size:o + 2 * G1.comp_size], bad[o + 2 * G1.comp_size:o + 3 * G1.comp_size] = b, a
+    with pytest.raises(pkg.PtauError) as e:
+        pkg.phase1_cli.verification_and_decompress(chal0, bytes(bad), prm0, ratio_check=True)
+    assert e.value.code == -6
+    assert not P.verify_chunk_ratios(p0, bytes(bad), rng=random.Random(3))
+    # the same tampering passes when the ratio check is skipped (--skip-ratio-check)
+    pkg.phase1_cli.verification_and_decompress(chal0, bytes(bad), prm0, ratio_check=False)
+    # tamper the G2 vector the same way
+    off2 = {nm: o for (nm, g, o, cnt) in p0.layout(True)[0]}["tau_g2"]
+    bad2 = bytearray(resp0)
+    s = G2.comp_size
+    bad2[off2 + s:off2 + 2 * s], bad2[off2 + 2 * s:off2 + 3 * s] = bad2[off2 + 2 * s:off2 + 3 * s], bad2[off2 + s:off2 + 2 * s]
+    with pytest.raises(pkg.PtauError) as e:
+        pkg.phase1_cli.verification_and_decompress(chal0, bytes(bad2), prm0, ratio_check=True)
+    assert e.value.code == -6
