@@ -138,39 +138,46 @@ struct TatePairing {
         }
         return out;
     }
-    // f_{r,P}(psi(Q)), P affine in G1, Q affine on the twist; neither at infinity
+    // f_{r,P}(psi(Q)) up to factors in Fq (killed by the final exponentiation), P affine in G1, Q affine on
+    // the twist, neither at infinity.  T runs in Jacobian coordinates, so no field inversion is needed:
+    //   doubling  (T=(X,Y,Z)):  N = 3X^2 + aZ^4,  Z3 = 2YZ,   l * Z3 Z^2 = (Z3 Z^2) y_Q - (N Z^2) x_Q + (N X - 2Y^2)
+    //   addition  (T + P):      H = x_P Z^2 - X,  R = y_P Z^3 - Y,  Z3 = Z H,   l * Z3 = Z3 y_Q - R x_Q + (R x_P - Z3 y_P)
     static E miller(const Affine<Fq> &P, const Affine<F2> &Q) {
+        using J = Jac<Fq, G1Cfg>;
         const E xq = embed(Q.x, 2 * PC::SIGN), yq = embed(Q.y, 3 * PC::SIGN);
         const Fq a = CurveConsts<Fq, G1Cfg>::coeff_a();
-        Fq xt = P.x, yt = P.y;
-        bool t_inf = false;
+        J T = J::from_affine(P);
         E f = E::one();
-        auto line = [&](const Fq &lam, const Fq &x0, const Fq &y0) {
+        auto line = [&](const Fq &cy, const Fq &cx, const Fq &c0) {   // cy*y_Q - cx*x_Q + c0
             E l;
-            for (int i = 0; i < K; i++) l.c[i] = Fq::sub(yq.c[i], Fq::mul(lam, xq.c[i]));
-            l.c[0] = Fq::add(Fq::sub(l.c[0], y0), Fq::mul(lam, x0));
+            for (int i = 0; i < K; i++) l.c[i] = Fq::sub(Fq::mul(cy, yq.c[i]), Fq::mul(cx, xq.c[i]));
+            l.c[0] = Fq::add(l.c[0], c0);
             return l;
         };
         for (int i = FrP::BITS - 2; i >= 0; i--) {
-            Fq xx = Fq::sqr(xt);
-            Fq lam = Fq::mul(Fq::add(Fq::add(Fq::dbl(xx), xx), a), Fq::inverse(Fq::dbl(yt)));
-            f = E::mul(E::sqr(f), line(lam, xt, yt));
-            Fq x3 = Fq::sub(Fq::sqr(lam), Fq::dbl(xt));
-            yt = Fq::sub(Fq::mul(lam, Fq::sub(xt, x3)), yt);
-            xt = x3;
+            {
+                Fq ZZ = Fq::sqr(T.Z), XX = Fq::sqr(T.X);
+                Fq N = Fq::add(Fq::dbl(XX), XX);
+                if constexpr (!G1Cfg::A_IS_ZERO) N = Fq::add(N, Fq::mul(a, Fq::sqr(ZZ)));
+                Fq Z3 = Fq::dbl(Fq::mul(T.Y, T.Z));
+                Fq c0 = Fq::sub(Fq::mul(N, T.X), Fq::dbl(Fq::sqr(T.Y)));
+                f = E::mul(E::sqr(f), line(Fq::mul(Z3, ZZ), Fq::mul(N, ZZ), c0));
+                T = J::dbl_inl(T);
+            }
             if ((FrP::MOD[i >> 5] >> (i & 31)) & 1u) {
-                if (xt == P.x) {   // T = -P: vertical line (eliminated); only at the last step, r*P = O
-                    t_inf = true;
+                Fq ZZ = Fq::sqr(T.Z);
+                Fq H = Fq::sub(Fq::mul(P.x, ZZ), T.X);
+                if (H.is_zero()) {   // T = -P: vertical line (eliminated); only at the last step, r*P = O
+                    T = J::infinity();
                     continue;
                 }
-                Fq lam2 = Fq::mul(Fq::sub(yt, P.y), Fq::inverse(Fq::sub(xt, P.x)));
-                f = E::mul(f, line(lam2, xt, yt));
-                Fq x4 = Fq::sub(Fq::sub(Fq::sqr(lam2), xt), P.x);
-                yt = Fq::sub(Fq::mul(lam2, Fq::sub(xt, x4)), yt);
-                xt = x4;
+                Fq R = Fq::sub(Fq::mul(P.y, Fq::mul(ZZ, T.Z)), T.Y);
+                Fq Z3 = Fq::mul(T.Z, H);
+                Fq c0 = Fq::sub(Fq::mul(R, P.x), Fq::mul(Z3, P.y));
+                f = E::mul(f, line(Z3, R, c0));
+                T = J::add_mixed_inl(T, P);
             }
         }
-        (void)t_inf;
         return f;
     }
     static E final_exp(const E &f) {
