@@ -187,6 +187,35 @@ int ptau_power_pairs(int curve, int group, const uint8_t *in, int compressed_in,
 int ptau_check_same_ratio(int curve, const uint8_t *g1_a, const uint8_t *g1_b, const uint8_t *g2_c,
                           const uint8_t *g2_d, char *err, size_t err_len);
 
+/* Phase1::initialization via phase1_cli::new_challenge (src/bin/new_setup.rs:105-109, verify_transcript.rs:322-326):
+ * blank BLAKE2b hash, then every element = the group generator, uncompressed (host only, no GPU needed).
+ * NOTE: the MNT4/MNT6 G2 generators are synthetic order-r points (arkworks' constants are not recoverable
+ * offline — DESIGN.md §2). */
+int ptau_new_challenge(const ptau_params *p, uint8_t *out, size_t out_len, char *err, size_t err_len);
+int ptau_new_challenge_file(const ptau_params *p, const char *challenge_path, const char *challenge_hash_path,
+                            char *err, size_t err_len);
+
+/* Phase1::aggregation via phase1_cli::combine (src/bin/control.rs:564-568, verify_transcript.rs:603-607):
+ * n_chunks compressed chunk responses -> one Full-mode UNCOMPRESSED accumulator (64 zero bytes | tauG1 |
+ * tauG2 | alphaG1 | betaG1 | betaG2 of chunk 0).  `full` must be Full-mode parameters. */
+int ptau_combine(const ptau_params *full, uint64_t chunk_size, const uint8_t *const *responses,
+                 const size_t *response_lens, uint64_t n_chunks, uint8_t *combined, size_t combined_len, int device,
+                 char *err, size_t err_len);
+
+/* Phase1::aggregate_verification via phase1_cli::transform_ratios (src/bin/control.rs:587-591,
+ * verify_transcript.rs:646-653, 812-822): full-length check_power_ratios of tauG1, tauG2, alphaG1, betaG1 and
+ * the betaG2 consistency check on a combined accumulator.  -> PTAU_E_INVALID_RATIO */
+int ptau_transform_ratios(const ptau_params *full, const uint8_t *combined, size_t combined_len, int check_input,
+                          int device, char *err, size_t err_len);
+
+/* Phase1::verification steps (1)-(2) (inside transform_pok_and_correctness, src/bin/contribute.rs:968-986):
+ * the three proofs of knowledge in the PublicKey at the tail of `response`, and for chunk 0 / Full mode the
+ * before/after checks (tauG1[1], alphaG1[0], betaG1[0], tauG2[1], betaG2 moved by exactly the public key).
+ * g2_s = the three compute_g2_s points (tau, alpha, beta), UNCOMPRESSED, computed by the host: hash_to_g2
+ * depends on arkworks' ChaCha-based G2 sampling and stays with key generation on the Rust side. */
+int ptau_verify_pok(const ptau_params *p, const uint8_t *challenge, size_t challenge_len, const uint8_t *response,
+                    size_t response_len, const uint8_t *g2_s, char *err, size_t err_len);
+
 /* Timings of the most recent compute call on `device`. */
 int ptau_last_timing(int device, ptau_timing *out);
 

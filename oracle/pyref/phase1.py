@@ -211,6 +211,16 @@ def synthetic_public_key(p: Params, tau: int, alpha: int, beta: int, digest: byt
     return serde.write_batch(G1, g1s, False) + serde.write_batch(G2, g2s, False)
 
 
+def synthetic_g2_s(p: Params, digest: bytes) -> bytes:
+    """The three g2_s base points matching synthetic_public_key (stand-in for compute_g2_s / hash_to_g2)."""
+    G2 = Group(p.curve, 2)
+    out = []
+    for pers in range(3):
+        k2 = int.from_bytes(hashlib.blake2b(bytes([pers]) + digest + b"g2", digest_size=64).digest(), "little") % p.curve.r
+        out.append(G2.mul(G2.gen, k2 or 1))
+    return serde.write_batch(G2, out, False)
+
+
 def aggregation(chunk_params, responses, full: Params) -> bytes:
     """Phase1::aggregation via phase1_cli::combine (control.rs:564-568; verify_transcript.rs:603-607):
     concatenate the per-chunk vectors of compressed responses into one full, UNCOMPRESSED

@@ -14,5 +14,5 @@ from ._lib import PtauError, load_library  # noqa: F401
 from .phase1_cli import (  # noqa: F401
     Phase1Parameters, PrivateKey, ContributionMode, ProvingSystem, CheckForCorrectness, BatchExpMode,
     SubgroupCheckMode, UseCompression, contribute, batch_exp_mode_from_str, subgroup_check_mode_from_str,
-    proving_system_from_str, curve_from_str, calculate_hash, transform_pok_and_correctness,
+    proving_system_from_str, curve_from_str, calculate_hash, transform_pok_and_correctness, new_challenge, combine, transform_ratios,
 )

@@ -19,7 +19,8 @@ DECLARED_SYMBOLS = [
     "ptau_strerror", "ptau_device_count", "ptau_device_info", "ptau_params_sizes", "ptau_point_size",
     "ptau_fr_limbs", "ptau_blake2b512", "ptau_apply_powers", "ptau_apply_powers_dev", "ptau_phase1_computation",
     "ptau_contribute_file", "ptau_decompress", "ptau_last_timing", "ptau_subgroup_check", "ptau_verify_chunk",
-    "ptau_transform_pok_and_correctness_file", "ptau_msm", "ptau_power_pairs", "ptau_check_same_ratio",
+    "ptau_transform_pok_and_correctness_file", "ptau_msm", "ptau_power_pairs", "ptau_check_same_ratio", "ptau_new_challenge", "ptau_new_challenge_file",
+    "ptau_combine", "ptau_transform_ratios", "ptau_verify_pok",
 ]
 
 
@@ -75,6 +76,11 @@ def load_library():
     L.ptau_msm.argtypes = [i, i, u8p, i, u64, u64p, u8p, i, i, cp, sz]
     L.ptau_power_pairs.argtypes = [i, i, u8p, i, u64, u8p, u64, u8p, u8p, i, cp, sz]
     L.ptau_check_same_ratio.argtypes = [i, u8p, u8p, u8p, u8p, cp, sz]
+    L.ptau_new_challenge.argtypes = [ctypes.POINTER(ptau_params), u8p, sz, cp, sz]
+    L.ptau_new_challenge_file.argtypes = [ctypes.POINTER(ptau_params), cp, cp, cp, sz]
+    L.ptau_combine.argtypes = [ctypes.POINTER(ptau_params), u64, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(sz), u64, u8p, sz, i, cp, sz]
+    L.ptau_transform_ratios.argtypes = [ctypes.POINTER(ptau_params), u8p, sz, i, i, cp, sz]
+    L.ptau_verify_pok.argtypes = [ctypes.POINTER(ptau_params), u8p, sz, u8p, sz, u8p, cp, sz]
     L.ptau_subgroup_check.argtypes = [i, i, u8p, i, u64, i, cp, sz]
     L.ptau_verify_chunk.argtypes = [ctypes.POINTER(ptau_params), u8p, sz, u8p, sz, u8p, sz, i, i, i, i, u8p, i, cp, sz]
     L.ptau_transform_pok_and_correctness_file.argtypes = [ctypes.POINTER(ptau_params), cp, cp, i, cp, cp, i, cp, cp, i, i, u8p, i, cp, sz]

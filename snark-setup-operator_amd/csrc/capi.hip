@@ -895,4 +895,220 @@ int ptau_check_same_ratio(int curve, const uint8_t *g1_a, const uint8_t *g1_b, c
     return PTAU_OK;
 }
 
+// ---- Phase1::initialization / aggregation / aggregate_verification / PoK --------------------------------------
+static const unsigned char *generator_bytes(int curve, int group) {
+    using G = ptau::Generators;
+    switch (curve * 2 + (group - 1)) {
+    case 0: return G::BLS_G1;   case 1: return G::BLS_G2;
+    case 2: return G::BW6_G1;   case 3: return G::BW6_G2;
+    case 4: return G::MNT4_G1;  case 5: return G::MNT4_G2;
+    case 6: return G::MNT6_G1;  case 7: return G::MNT6_G2;
+    }
+    return nullptr;
+}
+
+int ptau_new_challenge(const ptau_params *p, uint8_t *out, size_t out_len, char *errbuf, size_t err_len) {
+    Err err{errbuf, err_len};
+    int rc = check_params(p, err);
+    if (rc) return rc;
+    ptau_sizes sz;
+    ptau_params_sizes(p, &sz);
+    if (!out || out_len != sz.accumulator_size)
+        return err.fail(PTAU_E_LEN, "challenge buffer must be %llu bytes", (unsigned long long)sz.accumulator_size);
+    const GroupOps *g1 = get_ops(p->curve, 1), *g2 = get_ops(p->curve, 2);
+    const unsigned char *b1 = generator_bytes(p->curve, 1), *b2 = generator_bytes(p->curve, 2);
+    ptau_blake2b512(nullptr, 0, out);   // blank hash: the initial challenge extends nothing
+    uint8_t *po = out + 64;
+    auto fill = [&](const unsigned char *pt, int size, uint64_t n) {
+        for (uint64_t i = 0; i < n; i++, po += size) memcpy(po, pt, size);
+    };
+    fill(b1, g1->uncomp, sz.g1_chunk_size);
+    fill(b2, g2->uncomp, sz.other_chunk_size);
+    fill(b1, g1->uncomp, sz.other_chunk_size);
+    fill(b1, g1->uncomp, sz.other_chunk_size);
+    fill(b2, g2->uncomp, 1);
+    return PTAU_OK;
+}
+
+int ptau_new_challenge_file(const ptau_params *p, const char *challenge_path, const char *challenge_hash_path, char *errbuf,
+                            size_t err_len) {
+    Err err{errbuf, err_len};
+    int rc = check_params(p, err);
+    if (rc) return rc;
+    if (!challenge_path || !challenge_hash_path) return err.fail(PTAU_E_ARG, "null pointer argument");
+    ptau_sizes sz;
+    ptau_params_sizes(p, &sz);
+    MappedFile f;
+    if ((rc = f.create_new(challenge_path, sz.accumulator_size, err))) return rc;
+    if ((rc = ptau_new_challenge(p, (uint8_t *)f.p, f.len, errbuf, err_len))) return rc;
+    uint8_t digest[64];
+    ptau_blake2b512((const uint8_t *)f.p, f.len, digest);
+    if (msync(f.p, f.len, MS_SYNC)) return err.fail(PTAU_E_IO, "msync failed: %s", strerror(errno));
+    return write_small_file(challenge_hash_path, digest, 64, err);
+}
+
+int ptau_combine(const ptau_params *full, uint64_t chunk_size, const uint8_t *const *responses, const size_t *response_lens,
+                 uint64_t n_chunks, uint8_t *combined, size_t combined_len, int device, char *errbuf, size_t err_len) {
+    Err err{errbuf, err_len};
+    int rc = check_params(full, err);
+    if (rc) return rc;
+    if (full->contribution_mode != PTAU_MODE_FULL) return err.fail(PTAU_E_ARG, "combine needs Full-mode output parameters");
+    if (!responses || !response_lens || !combined || !chunk_size) return err.fail(PTAU_E_ARG, "null pointer argument");
+    ptau_sizes fs;
+    ptau_params_sizes(full, &fs);
+    if (combined_len != fs.accumulator_size)
+        return err.fail(PTAU_E_LEN, "combined buffer must be %llu bytes", (unsigned long long)fs.accumulator_size);
+    if (n_chunks != (fs.powers_g1_length + chunk_size - 1) / chunk_size)
+        return err.fail(PTAU_E_ARG, "expected %llu chunk responses", (unsigned long long)((fs.powers_g1_length + chunk_size - 1) / chunk_size));
+    const GroupOps *g1 = get_ops(full->curve, 1), *g2 = get_ops(full->curve, 2);
+    DeviceCtx *c;
+    if ((rc = ensure_ctx(device, c, err))) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(hipSetDevice(device));
+    c->timing = ptau_timing{};
+    memset(combined, 0, 64);
+    // destination vector bases in the full accumulator
+    uint8_t *d_tau_g1 = combined + 64;
+    uint8_t *d_tau_g2 = d_tau_g1 + fs.powers_g1_length * g1->uncomp;
+    uint8_t *d_alpha = d_tau_g2 + fs.powers_length * g2->uncomp;
+    uint8_t *d_beta = d_alpha + fs.powers_length * g1->uncomp;
+    uint8_t *d_beta_g2 = d_beta + fs.powers_length * g1->uncomp;
+    for (uint64_t k = 0; k < n_chunks; k++) {
+        ptau_params cp = *full;
+        cp.contribution_mode = PTAU_MODE_CHUNKED;
+        cp.chunk_index = k;
+        cp.chunk_size = chunk_size;
+        ptau_sizes cs;
+        ptau_params_sizes(&cp, &cs);
+        if (!responses[k] || response_lens[k] != cs.contribution_size)
+            return err.fail(PTAU_E_LEN, "response of chunk %llu is %zu bytes, expected %llu", (unsigned long long)k,
+                            response_lens[k], (unsigned long long)cs.contribution_size);
+        const uint8_t *pi = responses[k] + 64;
+        const uint64_t n1 = cs.g1_chunk_size, n2 = cs.other_chunk_size, s = cs.start;
+        struct { const GroupOps *ops; int group; uint64_t n; uint8_t *dst; } v[5] = {
+            {g1, 1, n1, d_tau_g1 + s * g1->uncomp}, {g2, 2, n2, d_tau_g2 + s * g2->uncomp},
+            {g1, 1, n2, d_alpha + s * g1->uncomp},  {g1, 1, n2, d_beta + s * g1->uncomp},
+            {g2, 2, (uint64_t)(k == 0 ? 1 : 0), d_beta_g2}};
+        for (int j = 0; j < 5; j++) {
+            const uint64_t stored = j == 4 ? 1 : v[j].n;   // every chunk stores beta_g2; only chunk 0's is kept
+            if (v[j].n &&
+                (rc = run_verify_vector(c, full->curve, v[j].group, v[j].ops, pi, v[j].dst, v[j].n, PTAU_CHECK_NO,
+                                        PTAU_SUBGROUP_NO, nullptr, 0, nullptr, nullptr, err)))
+                return rc;
+            pi += stored * v[j].ops->comp;
+        }
+    }
+    return PTAU_OK;
+}
+
+int ptau_transform_ratios(const ptau_params *full, const uint8_t *combined, size_t combined_len, int check_input, int device,
+                          char *errbuf, size_t err_len) {
+    Err err{errbuf, err_len};
+    int rc = check_params(full, err);
+    if (rc) return rc;
+    if (!combined) return err.fail(PTAU_E_ARG, "null pointer argument");
+    ptau_sizes fs;
+    ptau_params_sizes(full, &fs);
+    if (combined_len != fs.accumulator_size)
+        return err.fail(PTAU_E_LEN, "combined accumulator must be %llu bytes", (unsigned long long)fs.accumulator_size);
+    const GroupOps *g1 = get_ops(full->curve, 1), *g2 = get_ops(full->curve, 2);
+    const uint64_t n1 = fs.g1_chunk_size, n2 = fs.other_chunk_size;
+    const uint8_t *v_tau_g1 = combined + 64;
+    const uint8_t *v_tau_g2 = v_tau_g1 + n1 * g1->uncomp;
+    const uint8_t *v_alpha = v_tau_g2 + n2 * g2->uncomp;
+    const uint8_t *v_beta = v_alpha + n2 * g1->uncomp;
+    const uint8_t *v_beta_g2 = v_beta + n2 * g1->uncomp;
+    if (n1 < 2 || n2 < 2) return err.fail(PTAU_E_ARG, "accumulator too small for ratio checks");
+    struct { const GroupOps *ops; int group; const uint8_t *ptr; uint64_t n; const char *name; } vec[4] = {
+        {g1, 1, v_tau_g1, n1, "tau_g1"}, {g2, 2, v_tau_g2, n2, "tau_g2"}, {g1, 1, v_alpha, n2, "alpha_g1"}, {g1, 1, v_beta, n2, "beta_g1"}};
+    std::vector<uint8_t> pairs(4 * 2 * (size_t)g2->uncomp);
+    for (int k = 0; k < 4; k++) {
+        if (check_input == PTAU_CHECK_FULL || check_input == PTAU_CHECK_ONLY_IN_GROUP)
+            if ((rc = ptau_subgroup_check(full->curve, vec[k].group, vec[k].ptr, 0, vec[k].n, device, errbuf, err_len))) return rc;
+        uint8_t *pa = pairs.data() + (size_t)k * 2 * g2->uncomp;
+        if ((rc = ptau_power_pairs(full->curve, vec[k].group, vec[k].ptr, 0, vec[k].n, nullptr, 0, pa, pa + g2->uncomp, device,
+                                   errbuf, err_len)))
+            return rc;
+    }
+    // G1 vectors against (tauG2[0], tauG2[1]); tauG2 against (tauG1[0], tauG1[1]); betaG2 against betaG1[0]
+    for (int k : {0, 2, 3}) {
+        const uint8_t *pa = pairs.data() + (size_t)k * 2 * g2->uncomp;
+        rc = ptau_check_same_ratio(full->curve, pa, pa + g2->uncomp, v_tau_g2, v_tau_g2 + g2->uncomp, errbuf, err_len);
+        if (rc == PTAU_E_INVALID_RATIO) return err.fail(rc, "power ratio check failed for %s", vec[k].name);
+        if (rc) return rc;
+    }
+    {
+        const uint8_t *pa = pairs.data() + (size_t)1 * 2 * g2->uncomp;
+        rc = ptau_check_same_ratio(full->curve, v_tau_g1, v_tau_g1 + g1->uncomp, pa, pa + g2->uncomp, errbuf, err_len);
+        if (rc == PTAU_E_INVALID_RATIO) return err.fail(rc, "power ratio check failed for tau_g2");
+        if (rc) return rc;
+    }
+    // e(G1, betaG2) == e(betaG1[0], G2): (tauG1[0], betaG1[0]) ~ (tauG2[0], betaG2)
+    rc = ptau_check_same_ratio(full->curve, v_tau_g1, v_beta, v_tau_g2, v_beta_g2, errbuf, err_len);
+    if (rc == PTAU_E_INVALID_RATIO) return err.fail(rc, "beta_g2 is not consistent with beta_g1[0]");
+    return rc;
+}
+
+int ptau_verify_pok(const ptau_params *p, const uint8_t *challenge, size_t challenge_len, const uint8_t *response,
+                    size_t response_len, const uint8_t *g2_s, char *errbuf, size_t err_len) {
+    Err err{errbuf, err_len};
+    int rc = check_params(p, err);
+    if (rc) return rc;
+    if (!challenge || !response || !g2_s) return err.fail(PTAU_E_ARG, "null pointer argument");
+    ptau_sizes sz;
+    ptau_params_sizes(p, &sz);
+    if (challenge_len != sz.accumulator_size || response_len != sz.contribution_size)
+        return err.fail(PTAU_E_LEN, "challenge/response sizes do not match the parameters");
+    const GroupOps *g1 = get_ops(p->curve, 1), *g2 = get_ops(p->curve, 2);
+    const size_t u1 = g1->uncomp, u2 = g2->uncomp;
+    // PublicKey (uncompressed): tau_g1.0, tau_g1.1, alpha_g1.0, alpha_g1.1, beta_g1.0, beta_g1.1, tau_g2, alpha_g2, beta_g2
+    const uint8_t *pk = response + sz.contribution_size - sz.public_key_size;
+    const uint8_t *pk_g1[3][2], *pk_g2[3];
+    for (int x = 0; x < 3; x++) {
+        pk_g1[x][0] = pk + (2 * x) * u1;
+        pk_g1[x][1] = pk + (2 * x + 1) * u1;
+        pk_g2[x] = pk + 6 * u1 + x * u2;
+    }
+    static const char *names[3] = {"tau", "alpha", "beta"};
+    // (1) proofs of knowledge: (g1_s, x*g1_s) ~ (g2_s, x*g2_s)
+    for (int x = 0; x < 3; x++) {
+        rc = ptau_check_same_ratio(p->curve, pk_g1[x][0], pk_g1[x][1], g2_s + x * u2, pk_g2[x], errbuf, err_len);
+        if (rc == PTAU_E_INVALID_RATIO) return err.fail(rc, "proof of knowledge of %s is invalid", names[x]);
+        if (rc) return rc;
+    }
+    if (!(p->contribution_mode == PTAU_MODE_FULL || p->chunk_index == 0)) return PTAU_OK;
+    // (2) chunk 0: the response extends the challenge by exactly the key in the public key.
+    //     Needs a handful of response elements decompressed: done on the host (sqrt of ~5 points).
+    const uint64_t n1 = sz.g1_chunk_size, n2 = sz.other_chunk_size;
+    if (n1 < 2 || n2 < 2) return err.fail(PTAU_E_ARG, "chunk 0 too small for the before/after checks");
+    const uint8_t *b_tau_g1 = challenge + 64, *b_tau_g2 = b_tau_g1 + n1 * u1, *b_alpha = b_tau_g2 + n2 * u2,
+                  *b_beta = b_alpha + n2 * u1, *b_beta_g2 = b_beta + n2 * u1;
+    const size_t c1 = g1->comp, c2 = g2->comp;
+    const uint8_t *a_tau_g1 = response + 64, *a_tau_g2 = a_tau_g1 + n1 * c1, *a_alpha = a_tau_g2 + n2 * c2,
+                  *a_beta = a_alpha + n2 * c1, *a_beta_g2 = a_beta + n2 * c1;
+    std::vector<uint8_t> d(2 * u1 + u1 + u1 + 2 * u2 + u2);
+    uint8_t *da_tau_g1 = d.data(), *da_alpha = da_tau_g1 + 2 * u1, *da_beta = da_alpha + u1, *da_tau_g2 = da_beta + u1,
+            *da_beta_g2 = da_tau_g2 + 2 * u2;
+    {   // five elements: host-side sqrt (the pairing tail needs no GPU)
+        int bad = g1->decompress_host(a_tau_g1, da_tau_g1, 2, 1) | g1->decompress_host(a_alpha, da_alpha, 1, 1) |
+                  g1->decompress_host(a_beta, da_beta, 1, 1) | g2->decompress_host(a_tau_g2, da_tau_g2, 2, 1) |
+                  g2->decompress_host(a_beta_g2, da_beta_g2, 1, 1);
+        if ((rc = errbits_to_code(bad, err))) return rc;
+    }
+    // element 0 (tau^0) must be untouched
+    if (memcmp(da_tau_g1, b_tau_g1, u1) != 0 || memcmp(da_tau_g2, b_tau_g2, u2) != 0)
+        return err.fail(PTAU_E_INVALID_RATIO, "element 0 of tau_g1 / tau_g2 changed");
+    struct { const uint8_t *before, *after; int key; bool g1; const char *what; } chk[5] = {
+        {b_tau_g1 + u1, da_tau_g1 + u1, 0, true, "tau_g1[1]"}, {b_alpha, da_alpha, 1, true, "alpha_g1[0]"},
+        {b_beta, da_beta, 2, true, "beta_g1[0]"},             {b_tau_g2 + u2, da_tau_g2 + u2, 0, false, "tau_g2[1]"},
+        {b_beta_g2, da_beta_g2, 2, false, "beta_g2"}};
+    for (auto &k : chk) {
+        if (k.g1) rc = ptau_check_same_ratio(p->curve, k.before, k.after, g2_s + k.key * u2, pk_g2[k.key], errbuf, err_len);
+        else rc = ptau_check_same_ratio(p->curve, pk_g1[k.key][0], pk_g1[k.key][1], k.before, k.after, errbuf, err_len);
+        if (rc == PTAU_E_INVALID_RATIO) return err.fail(rc, "%s was not multiplied by the key in the public key", k.what);
+        if (rc) return rc;
+    }
+    return PTAU_OK;
+}
+
 }  // extern "C"

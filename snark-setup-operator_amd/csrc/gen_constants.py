@@ -17,6 +17,12 @@ MNT6_B1 = 1162590899954132115202734022401037471684116770178358464833890823541085
 BLS_G2_B1 = 155198655607781456406391640216936120121836107652948796323930557600032281009004493664981332883744016074664192874906
 
 
+# Synthetic order-r generators of the MNT twists (arkworks' constants are not recoverable offline):
+# smallest x = (k, 1[, 0]) on the twist, positive y, times the twist cofactor.
+MNT4_G2_GEN = ((19241021068095916780101505819204177866130316978498813175655453712234130792249572965936095408402742213223103260192441262888439414276965921531944942609754704672828990156287074618460540748574980646193593053348672676196473455297449, 37571968813056719349544804613609395755526305787839452593162691811172225578825852772050144361134352258939844287959560550034749844248343755134490338394667988539186355728895970457865941785683187620473448787127897942455665248375551), (23589630296873363831863652409442990017701166326539432024402785959446586334761491637547954312091039409900945953790575465129293333033671016576994774274066633181161735894331556574134695169051050976686432562161446479591360416615138, 20185621173490135311277358674180003121685302588984477921495339599873814308952582489044294387122623024266086590616061119415679839539450996087397501791402712466898936321241372074236777219971432749676198243752018672254846680537991))
+MNT6_G2_GEN = ((29198358678412327442734962858329560226529221072203506456026012448974205216981182326430452963416355393639268348853246220872774645199447843650057899436615551635917170214459877469820960613629590429199233247184212848085187308734929, 5999018000412277550478365752247211689696853783805982998351836252998281861610577852123252644775525980463600111418780194099963317946867954670821792886908172141813419565404494811506209266206591269999903100596739427595314458089519, 23036363772691094229836333217253237353920846158487310676871760642047832279183406136277001090285869741581273000600403111152094511074649824913321839863262906656729226549952126760622546375112636258358119156419276720729160639100672), (12522487755151452321636296110912153312587696989961702566133508697902026427396806962507244285498832447641578601706432705688833318733498102202120773626092164224621750103182935392734181664799052801736670403192038344073075905997843, 16235015760916115964926011096856921961118902124478830012533377841076941038656095966540337882684172623620414493625906317184520934808353542572158474378847050339489727226648236649815074973737903207021589886131177308741763891478875, 23675364518124042074447951143077219100080642308580948340331650285500567862191598861219028945929831519063354710694882580486644431500405814964247718872347363192237308655443507138052713813465575167843055486399098470156176028246725))
+
+
 def limbs(x, n):
     return ", ".join("0x%08xu" % ((x >> (32 * i)) & 0xFFFFFFFF) for i in range(n))
 
@@ -118,6 +124,46 @@ def main():
     out.append(pairing_cfg("Bw6PairingCfg", "Bw6Fq", BLS_Q, 6, -4, -1))
     out.append(pairing_cfg("Mnt4PairingCfg", "Mnt4Fq", MNT_B, 4, 13, -1))
     out.append(pairing_cfg("Mnt6PairingCfg", "Mnt6Fq", MNT_A, 6, 11, -1))
+    # ---- generators, arkworks uncompressed serialisation (x | y + sign flag): Phase1::initialization
+    def ser(p, coords_x, coords_y):
+        nb = (p.bit_length() + 7) // 8
+        neg_y = tuple((-c) % p for c in coords_y)
+        flag = 0x80 if tuple(reversed(coords_y)) > tuple(reversed(neg_y)) else 0
+        b = bytearray()
+        for c in coords_x:
+            b += c.to_bytes(nb, "little")
+        for c in coords_y:
+            b += c.to_bytes(nb, "little")
+        b[-1] |= flag
+        return bytes(b)
+
+    def gen_bytes(name, data):
+        return "static constexpr unsigned char %s[%d] = {%s};" % (name, len(data), ", ".join(str(v) for v in data))
+
+    BLS_G1 = ((0x008848defe740a67c8fc6225bf87ff5485951e2caa9d41bb188282c8bd37cb5cd5481512ffcd394eeab9b16eb21be9ef,),
+              (0x01914a69c5102eff1f674f5d30afeec4bd7fb348ca3e52d96d182ad44fb82305c2fe3d3634a9591afd82de55559c8ea6,))
+    BLS_G2 = ((0x018480be71c785fec89630a2a3841d01c565f071203e50317ea501f557db6b9b71889f52bb53540274e3e48f7c005196,
+               0x00ea6040e700403170dc5a51b1b140d5532777ee6651cecbe7223ece0799c9de5cf89984bff76fe6b26bfefa6ea16afe),
+              (0x00690d665d446f7bd960736bcbb2efb4de03ed7274b49a58e458c282f832d204f2cf88886d8c7c2ef094094409fd4ddf,
+               0x00f8169fd28355189e549da3151a70aa61ef11ac3d591bf12463b01acee304c24279b83f5e52270bd9a1cdd185eb8f93))
+    BW6_G1 = ((0x01075b020ea190c8b277ce98a477beaee6a0cfb7551b27f0ee05c54b85f56fc779017ffac15520ac11dbfcd294c2e746a17a54ce47729b905bd71fa0c9ea097103758f9a280ca27f6750dd0356133e82055928aca6af603f4088f3af66e5b43d,),
+              (0x0058b84e0a6fc574e6fd637b45cc2a420f952589884c9ec61a7348d2a2e573a3265909f1af7e0dbac5b8fa1771b5b806cc685d31717a4c55be3fb90b6fc2cdd49f9df141b3053253b2b08119cad0fb93ad1cb2be0b20d2a1bafc8f2db4e95363,))
+    BW6_G2 = ((0x0110133241d9b816c852a82e69d660f9d61053aac5a7115f4c06201013890f6d26b41c5dab3da268734ec3f1f09feb58c5bbcae9ac70e7c7963317a300e1b6bace6948cb3cd208d700e96efbc2ad54b06410cf4fe1bf995ba830c194cd025f1c,),
+              (0x0017c3357761369f8179eb10e4b6d2dc26b7cf9acec2181c81a78e2753ffe3160a1d86c80b95a59c94c97eb733293fef64f293dbd2c712b88906c170ffa823003ea96fcd504affc758aa2d3a3c5a02a591ec0594f9eac689eb70a16728c73b61,))
+    MNT4_G1 = ((7790163481385331313124631546957228376128961350185262705123068027727518350362064426002432450801002268747950550964579198552865939244360469674540925037890082678099826733417900510086646711680891516503232107232083181010099241949569,),
+               (6913648190367314284606685101150155872986263667483624713540251048208073654617802840433842931301128643140890502238233930290161632176167186761333725658542781350626799660920481723757654531036893265359076440986158843531053720994648,))
+    MNT6_G1 = ((16364236387491689444759057944334173579070747473738339749093487337644739228935268157504218078126401066954815152892688541654726829424326599038522503517302466226143788988217410842672857564665527806044250003808514184274233938437290,),
+               (4510127914410645922431074687553594593336087066778984214797709122300210966076979927285161950203037801392624582544098750667549188549761032654706830225743998064330900301346566408501390638273322467173741629353517809979540986561128,))
+    out.append("struct Generators {")
+    out.append("  " + gen_bytes("BLS_G1", ser(BLS_Q, *BLS_G1)))
+    out.append("  " + gen_bytes("BLS_G2", ser(BLS_Q, *BLS_G2)))
+    out.append("  " + gen_bytes("BW6_G1", ser(BW6_Q, *BW6_G1)))
+    out.append("  " + gen_bytes("BW6_G2", ser(BW6_Q, *BW6_G2)))
+    out.append("  " + gen_bytes("MNT4_G1", ser(MNT_A, *MNT4_G1)))
+    out.append("  " + gen_bytes("MNT4_G2", ser(MNT_A, *MNT4_G2_GEN)))
+    out.append("  " + gen_bytes("MNT6_G1", ser(MNT_B, *MNT6_G1)))
+    out.append("  " + gen_bytes("MNT6_G2", ser(MNT_B, *MNT6_G2_GEN)))
+    out.append("};")
     out.append("}  // namespace ptau")
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "curve_constants.inc")
     txt = "\n".join(out) + "\n"

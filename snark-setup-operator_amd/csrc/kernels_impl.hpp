@@ -389,6 +389,8 @@ struct GroupOps {
     void (*expect_infinity)(hipStream_t, const void *scratch, uint64_t n, int *err);
     void (*decompress)(hipStream_t, const uint8_t *in, uint8_t *out, uint64_t n, int check_nonzero, int *err);
     const uint32_t *group_order;   // r, canonical 32-bit limbs (fr_limbs32)
+    // O(1) host-side decompression for the pairing tail (a handful of public-key / head elements)
+    int (*decompress_host)(const uint8_t *in, uint8_t *out, uint64_t n, int check_nonzero);
 };
 
 template <class G>
@@ -458,6 +460,11 @@ struct Launch {
         if (!n) return;
         hipLaunchKernelGGL(decompress_kernel<G>, grid(n), dim3(256), 0, s, in, out, n, check_nonzero, err);
     }
+    static int decompress_host(const uint8_t *in, uint8_t *out, uint64_t n, int check_nonzero) {
+        int bad = 0;
+        for (uint64_t i = 0; i < n; i++) bad |= decompress_thread<G>(in, out, i, check_nonzero);
+        return bad;
+    }
     static GroupOps ops() {
         GroupOps o;
         o.comp = G::COMP;
@@ -476,6 +483,7 @@ struct Launch {
         o.expect_infinity = expect_infinity;
         o.decompress = decompress;
         o.group_order = Fr::Params::MOD;
+        o.decompress_host = decompress_host;
         return o;
     }
 };

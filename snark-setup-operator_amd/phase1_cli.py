@@ -300,6 +300,51 @@ def check_same_ratio(curve, g1_pair, g2_pair) -> bool:
     return True
 
 
+def new_challenge(challenge_filename, challenge_hash_filename, parameters: Phase1Parameters):
+    """phase1_cli::new_challenge (new_setup.rs:105-109)."""
+    L = _lib.load_library()
+    eb = _lib.errbuf()
+    _lib.check(L.ptau_new_challenge_file(ctypes.byref(parameters._c()), os.fsencode(challenge_filename),
+                                         os.fsencode(challenge_hash_filename), eb, len(eb)), eb)
+
+
+def initialization(parameters: Phase1Parameters) -> bytes:
+    """Phase1::initialization on a buffer."""
+    L = _lib.load_library()
+    out = ctypes.create_string_buffer(parameters.accumulator_size)
+    eb = _lib.errbuf()
+    _lib.check(L.ptau_new_challenge(ctypes.byref(parameters._c()), out, len(out), eb, len(eb)), eb)
+    return out.raw
+
+
+def combine(responses, chunk_size, full_parameters: Phase1Parameters, device=0) -> bytes:
+    """phase1_cli::combine / Phase1::aggregation on in-memory responses -> Full-mode uncompressed accumulator."""
+    L = _lib.load_library()
+    n = len(responses)
+    arr = (ctypes.c_char_p * n)(*responses)
+    lens = (ctypes.c_size_t * n)(*[len(r) for r in responses])
+    out = ctypes.create_string_buffer(full_parameters.accumulator_size)
+    eb = _lib.errbuf()
+    _lib.check(L.ptau_combine(ctypes.byref(full_parameters._c()), chunk_size, arr, lens, n, out, len(out), device, eb, len(eb)), eb)
+    return out.raw
+
+
+def transform_ratios(combined: bytes, check_input_correctness, full_parameters: Phase1Parameters, device=0):
+    """phase1_cli::transform_ratios / Phase1::aggregate_verification; raises PtauError(-6) on a bad ratio."""
+    L = _lib.load_library()
+    eb = _lib.errbuf()
+    _lib.check(L.ptau_transform_ratios(ctypes.byref(full_parameters._c()), combined, len(combined),
+                                       int(check_input_correctness), device, eb, len(eb)), eb)
+
+
+def verify_pok(challenge: bytes, response: bytes, g2_s: bytes, parameters: Phase1Parameters):
+    """Proof-of-knowledge + chunk-0 before/after checks of Phase1::verification; g2_s from the host's compute_g2_s."""
+    L = _lib.load_library()
+    eb = _lib.errbuf()
+    _lib.check(L.ptau_verify_pok(ctypes.byref(parameters._c()), challenge, len(challenge), response, len(response), g2_s,
+                                 eb, len(eb)), eb)
+
+
 def last_timing(device=0):
     t = _lib.ptau_timing()
     _lib.load_library().ptau_last_timing(device, ctypes.byref(t))

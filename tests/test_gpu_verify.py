@@ -232,3 +232,44 @@ def test_verify_with_ratio_check(name, pkg, golden):
     with pytest.raises(pkg.PtauError) as e:
         pkg.phase1_cli.verification_and_decompress(chal0, bytes(bad2), prm0, ratio_check=True)
     assert e.value.code == -6
+
+
+@pytest.mark.parametrize("name", ["bls12_377", "mnt6_753"])
+def test_round_combine_and_transform_ratios(name, pkg):
+    """A whole (tiny) round: new_challenge -> contribute every chunk with one key -> combine -> transform_ratios
+    (verify_transcript.rs:596-653 / control.rs:510-591).  combine is bit-exact vs the oracle's aggregation."""
+    c = CURVES[name]
+    power, cs = 3, 4
+    rng = random.Random(77)
+    key_scalars = [rng.randrange(1, c.r) for _ in range(3)]
+    full = pkg.Phase1Parameters.new_full(name, 0, power, cs)
+    n_chunks = -(-full.powers_g1_length // cs)
+    responses, oparams = [], []
+    for i in range(n_chunks):
+        prm = pkg.Phase1Parameters.new_chunk(name, 0, i, cs, 0, power, cs)
+        ch = pkg.phase1_cli.initialization(prm)
+        key = pkg.PrivateKey(*key_scalars, bytes(prm.public_key_size))
+        resp = bytearray(pkg.phase1_cli.computation(ch, prm, key))
+        resp[:64] = pkg.calculate_hash(ch)
+        responses.append(bytes(resp))
+        oparams.append(P.Params(c, P.CHUNKED, i, cs, power, cs))
+    combined = pkg.combine(responses, cs, full)
+    assert combined == P.aggregation(oparams, responses, P.Params(c, P.FULL, 0, cs, power, cs))
+    pkg.transform_ratios(combined, pkg.CheckForCorrectness.Full, full)
+    # a combined accumulator with two elements of alpha_g1 swapped is not geometric any more
+    G1, G2 = Group(c, 1), Group(c, 2)
+    off = 64 + full.powers_g1_length * G1.uncomp_size + full.powers_length * G2.uncomp_size
+    bad = bytearray(combined)
+    u = G1.uncomp_size
+    bad[off + u:off + 2 * u], bad[off + 2 * u:off + 3 * u] = bad[off + 2 * u:off + 3 * u], bad[off + u:off + 2 * u]
+    with pytest.raises(pkg.PtauError) as e:
+        pkg.transform_ratios(bytes(bad), pkg.CheckForCorrectness.No, full)
+    assert e.value.code == -6
+    # chunks contributed with DIFFERENT keys do not combine into a valid accumulator
+    prm1 = pkg.Phase1Parameters.new_chunk(name, 0, 1, cs, 0, power, cs)
+    other = pkg.PrivateKey(key_scalars[0] + 1, key_scalars[1], key_scalars[2], bytes(prm1.public_key_size))
+    r1 = bytearray(pkg.phase1_cli.computation(pkg.phase1_cli.initialization(prm1), prm1, other))
+    mixed = pkg.combine([responses[0], bytes(r1)] + responses[2:], cs, full)
+    with pytest.raises(pkg.PtauError) as e:
+        pkg.transform_ratios(mixed, pkg.CheckForCorrectness.No, full)
+    assert e.value.code == -6
