@@ -75,6 +75,43 @@ def cpu_baseline(sample_points, chal_bytes, start, tau):
                            % (sample_points, cores, dt)}
 
 
+def whole_chunk_extras(pkg, log2n, dev):
+    """Second half of the BASELINE metric ("chunks verified/sec") and the whole-chunk contribution, on chunk 0 of a
+    BLS12-377 power-`log2n` ceremony with chunk_size 2^log2n (3*2^n G1 + 2^n+1 G2 elements, HOST buffers: PCIe,
+    BLAKE2b and the pairing tail included where the call includes them).  Untimed set-up: new_challenge -> one
+    contribution; timed: verify (ratio_check on) and a second contribution."""
+    n = 1 << log2n
+    prm = pkg.Phase1Parameters.new_chunk("bls12_377", 0, 0, n, 0, log2n, n)
+    k0 = [det_scalar("bench/k0/%d" % i) for i in range(3)]
+    k1 = [det_scalar("bench/k1/%d" % i) for i in range(3)]
+    ch0 = pkg.phase1_cli.initialization(prm)
+    resp0 = bytearray(pkg.phase1_cli.computation(ch0, prm, pkg.PrivateKey(*k0, bytes(prm.public_key_size)), device=dev))
+    resp0[:64] = pkg.calculate_hash(ch0)
+    resp0 = bytes(resp0)
+    out = {"workload": "BLS12-377 power %d chunk 0, chunk_size 2^%d: %d G1 + %d G2 elements; challenge %d B, response %d B"
+                       % (log2n, log2n, 3 * n, n + 1, prm.accumulator_size, prm.contribution_size)}
+    t0 = time.perf_counter()
+    ch1 = pkg.phase1_cli.verification_and_decompress(ch0, resp0, prm, ratio_check=True, device=dev)
+    dt = time.perf_counter() - t0
+    tm = pkg.phase1_cli.last_timing(dev)
+    out["verify_chunk"] = {"seconds": dt, "chunks_verified_per_s": 1.0 / dt, "elements_per_s": (4 * n + 1) / dt,
+                           "includes": "hash chain (2 BLAKE2b, overlapped), sqrt decompression, non-zero + subgroup check of "
+                                       "every element, power_pairs of 4 vectors, 4 pairing checks, PCIe both ways",
+                           "device_ms": tm["kernel_ms"], "h2d_ms": tm["h2d_ms"], "d2h_ms": tm["d2h_ms"]}
+    t0 = time.perf_counter()
+    pkg.phase1_cli.verification_and_decompress(ch0, resp0, prm, ratio_check=False, device=dev)
+    dt2 = time.perf_counter() - t0
+    out["verify_chunk_skip_ratio_check"] = {"seconds": dt2, "chunks_verified_per_s": 1.0 / dt2}
+    t0 = time.perf_counter()
+    pkg.phase1_cli.computation(ch1, prm, pkg.PrivateKey(*k1, bytes(prm.public_key_size)), device=dev)
+    dt3 = time.perf_counter() - t0
+    tm = pkg.phase1_cli.last_timing(dev)
+    out["contribute_chunk"] = {"seconds": dt3, "chunks_per_s": 1.0 / dt3, "g1_equiv_updates_per_s": (4 * n + 1) / dt3,
+                               "includes": "Phase1::computation on host buffers: PCIe both ways, 5 vectors",
+                               "device_ms": tm["kernel_ms"], "h2d_ms": tm["h2d_ms"], "d2h_ms": tm["d2h_ms"]}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,6 +119,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log2-points", type=int, default=20)
     ap.add_argument("--cpu-sample", type=int, default=65536)
+    ap.add_argument("--no-extras", action="store_true", help="skip the whole-chunk contribute / verify measurements")
     args = ap.parse_args()
 
     import torch
@@ -158,6 +196,9 @@ def main():
         traffic, traffic_src = pmc_traffic()
         name = ctypes.create_string_buffer(128)
         L.ptau_device_info(dev, name, 128, None, None)
+        extras = None
+        if world == 1 and not args.no_extras:
+            extras = whole_chunk_extras(pkg, args.log2_points, dev)
         print(json.dumps({
             "metric": "G1 point-updates/sec per chunk (contribute)", "value": value, "unit": "G1 point-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -171,6 +212,7 @@ def main():
                          "normalize_kernel_ms": norm_ms / args.steps,
                          "note": "integer-ALU-bound by construction (~0.9 M 32-bit MACs per update vs 144 B): see DESIGN.md"},
             "cpu_baseline": base,
+            "extras": extras,
         }))
     if dist is not None:
         dist.destroy_process_group()

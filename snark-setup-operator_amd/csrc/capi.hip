@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -636,14 +637,18 @@ int ptau_contribute_file(const ptau_params *p, const char *challenge_path, const
         return err.fail(PTAU_E_LEN, "challenge file is %zu bytes, parameters require %llu", ch.len,
                         (unsigned long long)sz.accumulator_size);
     uint8_t digest[64];
-    ptau_blake2b512((const uint8_t *)ch.p, ch.len, digest);
-    if ((rc = write_small_file(challenge_hash_path, digest, 64, err))) return rc;
     if ((rc = resp.create_new(response_path, sz.contribution_size, err))) return rc;
     uint8_t *out = (uint8_t *)resp.p;
+    {   // BLAKE2b(challenge) on a host thread while the GPU updates the elements
+        const uint8_t *chp = (const uint8_t *)ch.p;
+        const size_t chl = ch.len;
+        auto fut = std::async(std::launch::async, [chp, chl, &digest] { ptau_blake2b512(chp, chl, digest); });
+        rc = ptau_phase1_computation(p, chp, chl, out, resp.len, tau, alpha, beta, check_input, device, errbuf, err_len);
+        fut.get();
+        if (rc) return rc;
+    }
+    if ((rc = write_small_file(challenge_hash_path, digest, 64, err))) return rc;
     memcpy(out, digest, 64);
-    if ((rc = ptau_phase1_computation(p, (const uint8_t *)ch.p, ch.len, out, resp.len, tau, alpha, beta, check_input, device,
-                                      errbuf, err_len)))
-        return rc;
     memcpy(out + sz.contribution_size - sz.public_key_size, public_key, public_key_len);
     ptau_blake2b512(out, resp.len, digest);
     if (msync(resp.p, resp.len, MS_SYNC)) return err.fail(PTAU_E_IO, "msync failed: %s", strerror(errno));
@@ -716,11 +721,23 @@ int ptau_verify_chunk(const ptau_params *p, const uint8_t *challenge, size_t cha
     if (response_len != sz.contribution_size)
         return err.fail(PTAU_E_LEN, "response is %zu bytes, parameters require %llu", response_len,
                         (unsigned long long)sz.contribution_size);
-    // hash chain: response[0..64) must be BLAKE2b(challenge)
-    uint8_t digest[64];
-    ptau_blake2b512(challenge, challenge_len, digest);
-    if (memcmp(digest, response, 64) != 0)
-        return err.fail(PTAU_E_HASH_CHAIN, "response does not start with the hash of the challenge it claims to extend");
+    // hash chain: response[0..64) must be BLAKE2b(challenge); new_challenge starts with BLAKE2b(response).
+    // Both digests run on host threads WHILE the GPU checks the elements (BLAKE2b is sequential, ~1 GB/s/core,
+    // and would otherwise cost as much as the device work — SURVEY §7 hard part 7).
+    auto fut_chain = std::async(std::launch::async, [=] {
+        uint8_t d[64];
+        ptau_blake2b512(challenge, challenge_len, d);
+        return memcmp(d, response, 64) == 0;
+    });
+    auto fut_resp = std::async(std::launch::async, [=] { ptau_blake2b512(response, response_len, new_challenge); });
+    struct Joiner {   // never leave a worker running past the caller's buffers
+        std::future<bool> &a;
+        std::future<void> &b;
+        ~Joiner() {
+            if (a.valid()) a.wait();
+            if (b.valid()) b.wait();
+        }
+    } joiner{fut_chain, fut_resp};
     const GroupOps *g1 = get_ops(p->curve, 1), *g2 = get_ops(p->curve, 2);
     DeviceCtx *c;
     if ((rc = ensure_ctx(device, c, err))) return rc;
@@ -762,23 +779,35 @@ int ptau_verify_chunk(const ptau_params *p, const uint8_t *challenge, size_t cha
         else if (tau_g2_check) g2_pair = tau_g2_check;
         if (!g2_pair)
             return err.fail(PTAU_E_ARG, "ratio_check on a chunk without tauG2 elements needs tau_g2_check (tauG2[0], tauG2[1])");
-        const int g1_vecs[3] = {0, 2, 3};
-        for (int k : g1_vecs) {
+        // the (up to four) pairing checks are independent: one host thread each
+        struct Job { const uint8_t *a, *b, *c2, *d2; const char *name; };
+        std::vector<Job> jobs;
+        for (int k : {0, 2, 3}) {
             if (vec[k].n < 2) continue;
-            const uint8_t *pa = pairs.data() + (size_t)k * 2 * g2->uncomp, *pb = pa + g2->uncomp;
-            rc = ptau_check_same_ratio(p->curve, pa, pb, g2_pair, g2_pair + g2->uncomp, errbuf, err_len);
-            if (rc == PTAU_E_INVALID_RATIO) return err.fail(rc, "power ratio check failed for %s", vec[k].name);
-            if (rc) return rc;
+            const uint8_t *pa = pairs.data() + (size_t)k * 2 * g2->uncomp;
+            jobs.push_back({pa, pa + g2->uncomp, g2_pair, g2_pair + g2->uncomp, vec[k].name});
         }
         if (n2 >= 2 && g1_pair) {
-            const uint8_t *pa = pairs.data() + (size_t)1 * 2 * g2->uncomp, *pb = pa + g2->uncomp;
-            rc = ptau_check_same_ratio(p->curve, g1_pair, g1_pair + g1->uncomp, pa, pb, errbuf, err_len);
-            if (rc == PTAU_E_INVALID_RATIO) return err.fail(rc, "power ratio check failed for tau_g2");
-            if (rc) return rc;
+            const uint8_t *pa = pairs.data() + (size_t)1 * 2 * g2->uncomp;
+            jobs.push_back({g1_pair, g1_pair + g1->uncomp, pa, pa + g2->uncomp, "tau_g2"});
         }
+        std::vector<std::future<int>> futs;
+        const int curve = p->curve;
+        for (auto &j : jobs)
+            futs.push_back(std::async(std::launch::async, [curve, j] { return ptau_check_same_ratio(curve, j.a, j.b, j.c2, j.d2, nullptr, 0); }));
+        int bad_rc = PTAU_OK;
+        const char *bad_name = nullptr;
+        for (size_t i = 0; i < futs.size(); i++) {
+            int r = futs[i].get();
+            if (r && !bad_rc) { bad_rc = r; bad_name = jobs[i].name; }
+        }
+        if (bad_rc == PTAU_E_INVALID_RATIO) return err.fail(bad_rc, "power ratio check failed for %s", bad_name);
+        if (bad_rc) return err.fail(bad_rc, "malformed ratio pair for %s", bad_name);
     }
     // new_challenge = BLAKE2b(response) | decompressed elements
-    ptau_blake2b512(response, response_len, new_challenge);
+    fut_resp.get();
+    if (!fut_chain.get())
+        return err.fail(PTAU_E_HASH_CHAIN, "response does not start with the hash of the challenge it claims to extend");
     return PTAU_OK;
 }
 
