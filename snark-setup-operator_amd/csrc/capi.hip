@@ -74,6 +74,17 @@ bool use_window_kernel() {
     return v;
 }
 
+// The GLV path (BLS12-377 G1) assumes its inputs lie in the prime-order subgroup, which holds for every
+// element of a verified challenge.  PTAU_GLV=0 selects the plain windowed multiplication, exact for ANY curve
+// point (BatchExpMode::Direct semantics); the subgroup check itself never uses GLV.
+int use_glv() {
+    static const int v = [] {
+        const char *e = getenv("PTAU_GLV");
+        return (e && strcmp(e, "0") == 0) ? 0 : 1;
+    }();
+    return v;
+}
+
 struct DeviceCtx {
     std::mutex mu;
     bool ready = false;
@@ -149,7 +160,7 @@ int run_apply_powers_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in,
         HIP_TRY(hipEventRecord(c->ev[0], c->stream));
         if (windowed)
             ops->window_scalar_mul(c->stream, d_in + off * isz, cin, c->scratch, c->wtab, m,
-                                   ptau::ScalarSource{ptau::SCALAR_TAU_TABLE, c->d_table, 0, 0, 0}, check_input, c->d_err);
+                                   ptau::ScalarSource{ptau::SCALAR_TAU_TABLE, c->d_table, 0, 0, 0}, check_input, use_glv(), c->d_err);
         else
             ops->scalar_mul(c->stream, d_in + off * isz, cin, c->scratch, m, c->d_table, check_input, c->d_err);
         HIP_TRY(hipEventRecord(c->ev[1], c->stream));
@@ -226,7 +237,7 @@ int run_msm_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, int cin,
         ptau::ScalarSource s2 = src;
         if (s2.mode == ptau::SCALAR_ARRAY) s2.ptr += off * ops->fr_limbs32;
         s2.index_base += off;
-        ops->window_scalar_mul(c->stream, d_in + off * isz, cin, S, c->wtab, m, s2, 0, c->d_err);
+        ops->window_scalar_mul(c->stream, d_in + off * isz, cin, S, c->wtab, m, s2, 0, use_glv(), c->d_err);
         // tree: m -> min(m,4096)·.. -> 64 -> 1
         const uint64_t t1 = std::min<uint64_t>(4096, (m + 15) / 16);
         ops->reduce_sum(c->stream, S, level, m, t1);
@@ -279,7 +290,7 @@ int run_subgroup_check_dev(DeviceCtx *c, int curve, int group, const GroupOps *o
             if ((rc = grow(c->scratch, c->scratch_cap, m * ops->jac_bytes, err))) return rc;
             if ((rc = grow(c->wtab, c->wtab_cap, m * ptau::WINDOW_ENTRIES * ops->jac_bytes, err))) return rc;
             ops->window_scalar_mul(c->stream, d_in + off * isz, cin, c->scratch, c->wtab, m,
-                                   ptau::ScalarSource{ptau::SCALAR_FIXED, c->d_table, 0, 0, 0}, 0, c->d_err);
+                                   ptau::ScalarSource{ptau::SCALAR_FIXED, c->d_table, 0, 0, 0}, 0, /*use_glv=*/0, c->d_err);
             ops->expect_infinity(c->stream, c->scratch, m, c->d_err);
         }
     }

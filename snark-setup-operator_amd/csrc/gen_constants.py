@@ -77,9 +77,18 @@ def main():
     out.append("using Mnt4Fr = Mnt6Fq;")
     out.append("using Mnt6Fr = Mnt4Fq;")
 
-    def coeffs(cname, fname, deg, a, b, nr):
+    def coeffs(cname, fname, deg, a, b, nr, glv=None):
         p, n, R = fields[fname]
         s = ["struct %s {" % cname]
+        s.append("  static constexpr bool HAS_GLV = %s;" % ("true" if glv else "false"))
+        if glv:
+            # phi(x, y) = (BETA x, y) = LAMBDA * (x, y) on the prime-order subgroup; k = k1 + k2*LAMBDA with
+            # k2 = floor(k / LAMBDA), both below 2^127.  GLV_M = floor(2^256 / LAMBDA) for the reciprocal division.
+            beta, lam = glv
+            assert lam.bit_length() <= 127
+            s.append("  static constexpr uint32_t GLV_BETA[%d] = {%s};" % (n, limbs(beta * R % p, n)))
+            s.append("  static constexpr uint32_t GLV_LAMBDA[4] = {%s};" % limbs(lam, 4))
+            s.append("  static constexpr uint32_t GLV_M[5] = {%s};" % limbs((1 << 256) // lam, 5))
         s.append("  static constexpr int DEG = %d;" % deg)
         s.append("  static constexpr bool A_IS_ZERO = %s;" % ("true" if not any(a) else "false"))
         s.append("  static constexpr int NR = %d;   // u^DEG = NR (small signed int)" % nr)
@@ -89,7 +98,14 @@ def main():
         s.append("};")
         return "\n".join(s)
 
-    out.append(coeffs("BlsG1Cfg", "BlsFq", 1, (0,), (1,), 0))
+    bls_x = 0x8508c00000000001
+    bls_lambda = bls_x * bls_x - 1
+    assert (bls_lambda * bls_lambda + bls_lambda + 1) % BLS_R == 0
+    g = 2
+    while pow(g, (BLS_Q - 1) // 3, BLS_Q) == 1:
+        g += 1
+    bls_beta = pow(g, 2 * (BLS_Q - 1) // 3, BLS_Q)   # the cube root of unity matching lambda = x^2 - 1 (tests check phi(G) = lambda G)
+    out.append(coeffs("BlsG1Cfg", "BlsFq", 1, (0,), (1,), 0, glv=(bls_beta, bls_lambda)))
     out.append(coeffs("BlsG2Cfg", "BlsFq", 2, (0, 0), (0, BLS_G2_B1), -5))
     out.append(coeffs("Bw6G1Cfg", "Bw6Fq", 1, (0,), (BW6_Q - 1,), 0))
     out.append(coeffs("Bw6G2Cfg", "Bw6Fq", 1, (0,), (4,), 0))

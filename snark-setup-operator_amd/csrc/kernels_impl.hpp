@@ -139,13 +139,76 @@ PTAU_HD uint32_t prf_word(uint64_t seed0, uint64_t seed1, uint64_t idx, int nl, 
     return (uint32_t)(splitmix64(z) >> 32);
 }
 
+// GLV decomposition for curves with the endomorphism phi(x, y) = (beta x, y) (BLS12-377 G1):
+// k = k1 + k2 * lambda with k2 = floor(k / lambda) through a 2^256 reciprocal; k1, k2 < 2^127.
+// Valid ONLY for points of the prime-order subgroup (phi = [lambda] there): callers select it for the
+// tau-update / MSM of verified elements, never for the subgroup check itself.
+template <class Cfg>
+PTAU_HD void glv_decompose(const uint32_t (&k)[8], uint32_t (&k1)[4], uint32_t (&k2)[4]) {
+    // qhat = (k * M) >> 256, M = floor(2^256 / lambda) (5 limbs)
+    uint32_t prod[13];
+    {
+        uint64_t acc = 0, carry_hi = 0;
+        for (int col = 0; col < 13; col++) {
+            uint64_t lo = acc, hi = carry_hi;
+            acc = 0;
+            carry_hi = 0;
+            for (int i = 0; i < 8; i++) {
+                int j = col - i;
+                if (j < 0 || j >= 5) continue;
+                uint64_t t = (uint64_t)k[i] * Cfg::GLV_M[j];
+                lo += t;
+                if (lo < t) hi++;
+            }
+            prod[col] = (uint32_t)lo;
+            acc = (lo >> 32) | (hi << 32);
+            carry_hi = hi >> 32;
+        }
+    }
+    uint32_t qh[5] = {prod[8], prod[9], prod[10], prod[11], prod[12]};
+    // rem = k - qhat * lambda   (fits 5 limbs: < 3 lambda < 2^128)
+    uint32_t ql[5];
+    {
+        uint64_t acc = 0, carry_hi = 0;
+        for (int col = 0; col < 5; col++) {
+            uint64_t lo = acc, hi = carry_hi;
+            acc = 0;
+            carry_hi = 0;
+            for (int i = 0; i < 5; i++) {
+                int j = col - i;
+                if (j < 0 || j >= 4) continue;
+                uint64_t t = (uint64_t)qh[i] * Cfg::GLV_LAMBDA[j];
+                lo += t;
+                if (lo < t) hi++;
+            }
+            ql[col] = (uint32_t)lo;
+            acc = (lo >> 32) | (hi << 32);
+            carry_hi = hi >> 32;
+        }
+    }
+    uint32_t rem[5];
+    uint32_t br = 0;
+    for (int i = 0; i < 5; i++) rem[i] = subb(k[i], ql[i], br);
+    // at most two corrections
+    for (int it = 0; it < 3; it++) {
+        uint32_t t[5];
+        uint32_t b2 = 0;
+        for (int i = 0; i < 5; i++) t[i] = subb(rem[i], i < 4 ? Cfg::GLV_LAMBDA[i] : 0u, b2);
+        if (b2) break;   // rem < lambda
+        for (int i = 0; i < 5; i++) rem[i] = t[i];
+        uint32_t c = 1;
+        for (int i = 0; i < 5; i++) qh[i] = addc(qh[i], 0u, c);
+    }
+    for (int i = 0; i < 4; i++) { k1[i] = rem[i]; k2[i] = qh[i]; }
+}
+
 constexpr int WINDOW_BITS = 4;
 constexpr int WINDOW_ENTRIES = 8;
 
 template <class G>
 PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typename G::J *scratch,
                                      typename G::J *wtab, uint64_t n, uint64_t i, const ScalarSource &src,
-                                     int check_input) {
+                                     int check_input, int use_glv = 0) {
     using Fr = typename G::Fr;
     using F = typename G::F;
     using A = typename G::A;
@@ -183,6 +246,46 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
         Fr ek = scalar_for_index<Fr>(src.ptr, i);
         ek.to_canonical(k);
     }
+    using Cfg = typename J::CfgT;
+    if constexpr (Cfg::HAS_GLV && NL == 8) {
+        if (use_glv) {
+            // k = k1 + k2*lambda, k*P = k1*P + k2*phi(P), phi(X, Y, Z) = (beta X, Y, Z): 128-bit interleaved windows
+            uint32_t kk[2][4];
+            glv_decompose<Cfg>(k, kk[0], kk[1]);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                uint32_t c2 = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) kk[h][j] = addc(kk[h][j], 0x88888888u, c2);   // k1, k2 < 2^126.2: no carry out
+            }
+            F beta;
+#pragma unroll
+            for (int j = 0; j < F::N; j++) beta.l[j] = Cfg::GLV_BETA[j];
+            J acc = J::infinity();
+            for (int w = 31; w >= 0; w--) {
+                if (!acc.is_inf()) {
+#pragma nounroll
+                    for (int d = 0; d < WINDOW_BITS; d++) acc = J::dbl(acc);
+                }
+#pragma nounroll
+                for (int h = 0; h < 2; h++) {
+                    uint32_t limb = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) limb = (j == (w >> 3)) ? (h ? kk[1][j] : kk[0][j]) : limb;
+                    int dgt = (int)((limb >> ((w & 7) * 4)) & 15u) - 8;
+                    if (dgt != 0) {
+                        int mag = dgt < 0 ? -dgt : dgt;
+                        J ent = wtab[(uint64_t)(mag - 1) * n + i];
+                        if (h) ent.X = F::mul(ent.X, beta);
+                        if (dgt < 0) ent.Y = F::neg(ent.Y);
+                        acc = J::add(acc, ent);
+                    }
+                }
+            }
+            scratch[i] = acc;
+            return 0;
+        }
+    }
     uint32_t c = 0;
 #pragma unroll
     for (int j = 0; j < NL; j++) k[j] = addc(k[j], 0x88888888u, c);
@@ -211,10 +314,10 @@ template <class G>
 __global__ void __launch_bounds__(256)
 window_scalar_mul_kernel(const uint8_t *__restrict__ in, int compressed_in, typename G::J *__restrict__ scratch,
                          typename G::J *__restrict__ wtab, uint64_t n, ScalarSource src, int check_input,
-                         int *__restrict__ err) {
+                         int use_glv, int *__restrict__ err) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    int bad = window_scalar_mul_thread<G>(in, compressed_in, scratch, wtab, n, i, src, check_input);
+    int bad = window_scalar_mul_thread<G>(in, compressed_in, scratch, wtab, n, i, src, check_input, use_glv);
     if (bad) atomicOr(err, bad);
 }
 
@@ -379,7 +482,7 @@ struct GroupOps {
     void (*scalar_mul)(hipStream_t, const uint8_t *in, int cin, void *scratch, uint64_t n, const uint32_t *table,
                        int check_input, int *err);
     void (*window_scalar_mul)(hipStream_t, const uint8_t *in, int cin, void *scratch, void *wtab, uint64_t n,
-                              ScalarSource src, int check_input, int *err);
+                              ScalarSource src, int check_input, int use_glv, int *err);
     void (*reduce_sum)(hipStream_t, const void *in, void *out, uint64_t n, uint64_t T);
     void (*on_curve)(hipStream_t, const uint8_t *in, uint64_t n, int *err);
     void (*fixed_scalar_mul)(hipStream_t, const uint8_t *in, int cin, void *scratch, uint64_t n,
@@ -427,10 +530,10 @@ struct Launch {
                            check_input, err);
     }
     static void window_scalar_mul(hipStream_t s, const uint8_t *in, int cin, void *scratch, void *wtab, uint64_t n,
-                                  ScalarSource src, int check_input, int *err) {
+                                  ScalarSource src, int check_input, int use_glv, int *err) {
         if (!n) return;
         hipLaunchKernelGGL(window_scalar_mul_kernel<G>, grid(n), dim3(256), 0, s, in, cin, (typename G::J *)scratch,
-                           (typename G::J *)wtab, n, src, check_input, err);
+                           (typename G::J *)wtab, n, src, check_input, use_glv, err);
     }
     static void reduce_sum(hipStream_t s, const void *in, void *out, uint64_t n, uint64_t T) {
         if (!T) return;

@@ -50,7 +50,8 @@ static int run(const std::string &op, uint64_t n, uint64_t start, int cin, int c
         } else {
             std::vector<typename G::J> wtab(n * WINDOW_ENTRIES);
             for (uint64_t i = 0; i < n; i++)
-                bad |= window_scalar_mul_thread<G>(in.data(), cin, scratch.data(), wtab.data(), n, i, ScalarSource{SCALAR_TAU_TABLE, table.data(), 0, 0, 0}, 0);
+                bad |= window_scalar_mul_thread<G>(in.data(), cin, scratch.data(), wtab.data(), n, i, ScalarSource{SCALAR_TAU_TABLE, table.data(), 0, 0, 0}, 0,
+                                                       getenv("PTAU_GLV") && !strcmp(getenv("PTAU_GLV"), "0") ? 0 : 1);
         }
         uint64_t T = (n + 3) / 4;
         for (uint64_t t = 0; t < T; t++) bad |= normalize_thread<G>(scratch.data(), pre.data(), out.data(), cout, n, T, t, 0);
