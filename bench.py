@@ -57,7 +57,11 @@ def pmc_traffic():
         import glob
         f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))[-1]
         d = json.load(open(f))
-        return d["kernels"]["scalar_mul_kernel"]["hbm_bytes_per_launch"], os.path.basename(f)
+        k = d["kernels"]
+        for name in ("window_scalar_mul_kernel<BlsG1>", "window_scalar_mul_kernel", "scalar_mul_kernel"):
+            if name in k and "hbm_bytes_per_launch" in k[name]:
+                return k[name]["hbm_bytes_per_launch"], os.path.basename(f)
+        return None, None
     except Exception:
         return None, None
 
@@ -202,13 +206,13 @@ def main():
         print(json.dumps({
             "metric": "G1 point-updates/sec per chunk (contribute)", "value": value, "unit": "G1 point-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (377-bit Montgomery)",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
             "data": "synthetic",
             "config": {"workload": "BLS12-377 phase-1 power 20, chunk_size 2^20: tauG1 vector of one chunk per GPU "
                                    "(2^%d points, uncompressed in -> compressed out, HBM-resident)" % args.log2_points,
                        "points_per_step_per_gpu": n, "device": name.value.decode(), "parity": "bit-exact vs CPU oracle on %d sampled points" % sample},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "scalar_mul_kernel<BLS12-377 G1>", "kernel_ms": smul_ms / args.steps,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "window_scalar_mul_kernel<BLS12-377 G1>", "kernel_ms": smul_ms / args.steps,
                          "normalize_kernel_ms": norm_ms / args.steps,
                          "note": "integer-ALU-bound by construction (~0.9 M 32-bit MACs per update vs 144 B): see DESIGN.md"},
             "cpu_baseline": base,

@@ -61,6 +61,11 @@ PTAU_HD void mac_pair(Acc96 &a, uint32_t x, uint32_t y, uint32_t z, uint32_t c) 
     mac_vv(a, z, c);
 #endif
 }
+PTAU_HD void acc_add32(Acc96 &a, uint32_t x) {
+    uint64_t t = a.lo + x;
+    a.hi += t < a.lo ? 1u : 0u;
+    a.lo = t;
+}
 PTAU_HD void acc_shift(Acc96 &a) {
     a.lo = (a.lo >> 32) | ((uint64_t)a.hi << 32);
     a.hi = 0;
@@ -169,6 +174,59 @@ struct Fp {
 #pragma unroll
         for (int i = 0; i < N; i++) out[i] = keep ? r[i] : u[i];
     }
+    // Montgomery square: the cross products a_j a_k (j < k) are taken once against d = 2a (2a < 2^(32N)
+    // for every supported modulus), so a square issues N(N+1)/2 + N^2 MACs instead of 2 N^2.
+    // d is 2a as ONE integer (limb j carries bit 31 of limb j-1 = c_{j-1}), hence
+    //   2 sum_{j<k} a_j a_k B^(j+k) = sum_{j<k} d_j a_k B^(j+k) + sum_k c_{k-1} a_k B^(2k):
+    // the diagonal column 2k takes a_k^2 plus a_k when bit 31 of a_{k-1} is set.
+    PTAU_HD static void fips_sqr(const uint32_t (&a)[N], uint32_t (&out)[N]) {
+        static_assert(P::BITS + 1 <= 32 * N, "2a must fit N limbs");
+        uint32_t d[N], m[N], r[N];
+#pragma unroll
+        for (int i = 0; i < N; i++) d[i] = (a[i] << 1) | (i ? (a[i - 1] >> 31) : 0u);
+        Acc96 acc{0, 0};
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+#pragma unroll
+            for (int j = 0; j < i; j++) {
+                if (2 * j < i) mac_pair(acc, d[j], a[i - j], m[j], P::MOD[i - j]);
+                else mac_vs(acc, m[j], P::MOD[i - j]);
+            }
+            if ((i & 1) == 0) {
+                mac_vv(acc, a[i / 2], a[i / 2]);
+                if (i) acc_add32(acc, (0u - (a[i / 2 - 1] >> 31)) & a[i / 2]);
+            }
+            m[i] = (uint32_t)acc.lo * P::INV;
+            mac_vs(acc, m[i], P::MOD[0]);
+            acc_shift(acc);
+        }
+#pragma unroll
+        for (int i = N; i < 2 * N; i++) {
+#pragma unroll
+            for (int j = i - N + 1; j < N; j++) {
+                if (2 * j < i) mac_pair(acc, d[j], a[i - j], m[j], P::MOD[i - j]);
+                else mac_vs(acc, m[j], P::MOD[i - j]);
+            }
+            if ((i & 1) == 0 && i / 2 < N) {
+                mac_vv(acc, a[i / 2], a[i / 2]);
+                acc_add32(acc, (0u - (a[i / 2 - 1] >> 31)) & a[i / 2]);
+            }
+            r[i - N] = (uint32_t)acc.lo;
+            acc_shift(acc);
+        }
+        uint32_t u[N];
+        uint32_t br = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) u[i] = subb(r[i], P::MOD[i], br);
+        const bool keep = br && (uint32_t)acc.lo == 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) out[i] = keep ? r[i] : u[i];
+    }
+    PTAU_HD static Fp sqr_inl(const Fp &a) {
+        Fp r;
+        fips_sqr(a.l, r.l);
+        return r;
+    }
     PTAU_HD static Fp mul_inl(const Fp &a, const Fp &b) {
         Fp r;
         fips_mul(a.l, b.l, r.l);
@@ -201,7 +259,31 @@ struct Fp {
             return r;
         }
     }
-    PTAU_HD static Fp sqr(const Fp &a) { return mul(a, a); }
+    __host__ __device__ __noinline__ static VecN sqr_vec(VecN a) {
+        uint32_t x[N], r[N];
+#pragma unroll
+        for (int i = 0; i < N; i++) x[i] = a[i];
+        fips_sqr(x, r);
+        VecN o;
+#pragma unroll
+        for (int i = 0; i < N; i++) o[i] = r[i];
+        return o;
+    }
+    __host__ __device__ __noinline__ static Fp sqr_out(const Fp &a) { return sqr_inl(a); }
+    PTAU_HD static Fp sqr(const Fp &a) {
+        if constexpr (MUL_OUT_OF_LINE) {
+            return sqr_out(a);
+        } else {
+            VecN x;
+#pragma unroll
+            for (int i = 0; i < N; i++) x[i] = a.l[i];
+            VecN o = sqr_vec(x);
+            Fp r;
+#pragma unroll
+            for (int i = 0; i < N; i++) r.l[i] = o[i];
+            return r;
+        }
+    }
 
     // small signed constant multiple via double-and-add (used for extension-field non-residues)
     PTAU_HD static Fp mul_small(const Fp &a, int k) {

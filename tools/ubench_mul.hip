@@ -17,6 +17,8 @@ __global__ void __launch_bounds__(256) k(F *io, int iters) {
     for (int it = 0; it < iters; it++) {
         if (MODE == 0) { a = F::mul(a, b); b = F::mul(b, a); }
         if (MODE == 1) { a = F::mul_inl(a, b); b = F::mul_inl(b, a); }
+        if (MODE == 2) { a = F::sqr(a); b = F::sqr(b); }
+        if (MODE == 3) { a = F::sqr_inl(a); b = F::sqr_inl(b); }
     }
     io[256 + t] = F::add(a, b);
 }
@@ -42,10 +44,12 @@ int main() {
     for (int i = 0; i < 256; i++) { uint32_t c[12]; for (int j = 0; j < 12; j++) c[j] = (i * 2654435761u + j * 40503u) ^ (j << 20); c[11] &= 0x00ffffff; h[i] = F::from_canonical(c); }
     F *d; hipMalloc(&d, sizeof(F) * (256 + 4096 * 256));
     hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice);
-    F o0[256], o1[256];
+    F o0[256], o1[256], o2[256], o3[256];
     for (int blocks : {1024, 2048, 3072}) {
         run<0>("FIPS call", d, blocks, o0);
         run<1>("FIPS inline", d, blocks, o1);
+        run<2>("SQR call", d, blocks, o2);
+        run<3>("SQR inline", d, blocks, o3);
     }
     // host reference: the same templates compiled for the CPU
     int bad = 0;
@@ -54,6 +58,10 @@ int main() {
         for (int it = 0; it < ITER; it++) { a = F::mul_inl(a, b); b = F::mul_inl(b, a); }
         F e = F::add(a, b);
         if (!(e == o0[i]) || !(e == o1[i])) bad++;
+        F a2 = h[i & 255], b2 = h[(i + 1) & 255];
+        for (int it = 0; it < ITER; it++) { a2 = F::mul_inl(a2, a2); b2 = F::mul_inl(b2, b2); }
+        F e2 = F::add(a2, b2);
+        if (!(e2 == o2[i]) || !(e2 == o3[i])) bad++;
     }
     printf("mismatches vs host: %d\n", bad);
     return bad != 0;
