@@ -83,6 +83,7 @@ typedef struct ptau_timing {
     double h2d_ms, kernel_ms, d2h_ms; /* summed over the call */
     double scalar_mul_ms, normalize_ms; /* the two kernels of the tau-update */
     uint64_t points;                  /* group elements processed */
+    double decompress_ms, subgroup_ms, msm_ms; /* verify path: sqrt, subgroup checks, bucket MSMs (parts of kernel_ms) */
 } ptau_timing;
 
 const char *ptau_strerror(int code);

@@ -46,7 +46,8 @@ class ptau_sizes(ctypes.Structure):
 
 class ptau_timing(ctypes.Structure):
     _fields_ = [("h2d_ms", ctypes.c_double), ("kernel_ms", ctypes.c_double), ("d2h_ms", ctypes.c_double),
-                ("scalar_mul_ms", ctypes.c_double), ("normalize_ms", ctypes.c_double), ("points", ctypes.c_uint64)]
+                ("scalar_mul_ms", ctypes.c_double), ("normalize_ms", ctypes.c_double), ("points", ctypes.c_uint64),
+                ("decompress_ms", ctypes.c_double), ("subgroup_ms", ctypes.c_double), ("msm_ms", ctypes.c_double)]
 
 
 def load_library():

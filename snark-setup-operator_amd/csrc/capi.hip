@@ -96,6 +96,8 @@ struct DeviceCtx {
     int *d_err = nullptr;
     void *d_in = nullptr, *d_out = nullptr;   // staging for the host-buffer entry points
     void *d_small = nullptr;                  // single-point results (MSM)
+    void *msm_ws = nullptr;                   // bucket-MSM workspace
+    size_t msm_cap = 0;
     size_t in_cap = 0, out_cap = 0;
     ptau_timing timing = {};
 };
@@ -211,11 +213,162 @@ int run_apply_powers_host(DeviceCtx *c, const GroupOps *ops, const uint8_t *in, 
     return PTAU_OK;
 }
 
-// sum_i k_i * P_i over n device-resident points -> ONE serialized affine point in host memory.
-// Round-1 form: n windowed scalar multiplications (the K1 kernel) followed by a tree of Jacobian sums;
-// a bucket (Pippenger) accumulation is the planned replacement.  Caller holds the device mutex.
-int run_msm_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, int cin, uint64_t n, ptau::ScalarSource src,
-                uint8_t *out_host, int cout, const Err &err) {
+// Exclusive prefix sums over m bucket counts: offsets[0..m] (entries; offsets[m] = total), cursor[j] = offsets[j]
+// (the scatter pass bumps the cursor with atomics) and run_offsets[0..m] over ceil(count / MSM_RUN) (the runs the
+// accumulate pass works on).  One workgroup: m is at most a few hundred thousand.
+__global__ void __launch_bounds__(1024) exclusive_scan_kernel(uint32_t *__restrict__ counts_cursor, uint32_t *__restrict__ offsets,
+                                                              uint32_t *__restrict__ run_offsets, uint32_t m) {
+    __shared__ uint32_t part[1024], rpart[1024];
+    const uint32_t t = threadIdx.x, per = (m + 1023u) / 1024u;
+    const uint32_t lo = t * per < m ? t * per : m, hi = lo + per < m ? lo + per : m;
+    uint32_t sum = 0, rsum = 0;
+    for (uint32_t j = lo; j < hi; j++) {
+        const uint32_t cnt = counts_cursor[j];
+        sum += cnt;
+        rsum += (cnt + ptau::MSM_RUN - 1) / ptau::MSM_RUN;
+    }
+    part[t] = sum;
+    rpart[t] = rsum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {   // Hillis-Steele inclusive scan of the 1024 partials
+        const uint32_t v = t >= d ? part[t - d] : 0, rv = t >= d ? rpart[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        rpart[t] += rv;
+        __syncthreads();
+    }
+    uint32_t run = t ? part[t - 1] : 0, rrun = t ? rpart[t - 1] : 0;
+    for (uint32_t j = lo; j < hi; j++) {
+        const uint32_t cnt = counts_cursor[j];
+        offsets[j] = run;
+        run_offsets[j] = rrun;
+        counts_cursor[j] = run;
+        run += cnt;
+        rrun += (cnt + ptau::MSM_RUN - 1) / ptau::MSM_RUN;
+    }
+    if (t == 1023) {
+        offsets[m] = part[1023];
+        run_offsets[m] = rpart[1023];
+    }
+}
+
+// PTAU_MSM=naive selects the round-1 form (n windowed scalar multiplications + a tree of sums) for A/B runs.
+bool use_bucket_msm() {
+    static const bool v = [] {
+        const char *e = getenv("PTAU_MSM");
+        return !(e && strcmp(e, "naive") == 0);
+    }();
+    return v;
+}
+
+constexpr uint64_t MSM_SLICE_POINTS = 1ull << 22;   // points per bucket pass (u32 sort indices, bounded workspace)
+
+ptau::MsmPlan msm_plan(uint64_t m, int scalar_bits) {
+    int lg = 0;
+    while ((2ull << lg) <= m) lg++;
+    ptau::MsmPlan pl;
+    pl.c = std::max(2, std::min(16, lg - 4));    // ~32 points per bucket; >= 2^18 bucket threads at 2^20 points
+    pl.W = (scalar_bits + 1 + pl.c - 1) / pl.c;
+    pl.B = 1u << (pl.c - 1);
+    pl.seg = std::min<uint32_t>(pl.B, 8);
+    return pl;
+}
+
+// sum_i k_i * P_i (i < n) -> ONE serialized affine point in host memory; with out_b also the SHIFTED sum
+// sum_i k_i * P_{i+1} (power_pairs: d_in must then hold n + 1 points).  Bucket method (K4); caller holds the
+// device mutex.
+int run_msm_bucket_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, int cin, uint64_t n, ptau::ScalarSource src,
+                       uint8_t *out_a, uint8_t *out_b, int cout, const Err &err) {
+    const int isz = cin ? ops->comp : ops->uncomp, osz = cout ? ops->comp : ops->uncomp;
+    const int nsum = out_b ? 2 : 1;
+    const int scalar_bits = src.mode == ptau::SCALAR_PRF ? ptau::PRF_BITS : ops->fr_bits;
+    const uint64_t nslice = n ? (n + MSM_SLICE_POINTS - 1) / MSM_SLICE_POINTS : 1;
+    const uint64_t cap = std::min<uint64_t>(std::max<uint64_t>(n, 1), MSM_SLICE_POINTS);
+    const ptau::MsmPlan big = msm_plan(cap, scalar_bits);
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    // workspace carve-up (sized for the largest slice; W*B peaks at the largest c)
+    size_t wb_max = 0, w_max = 0;
+    for (uint64_t m : {cap, n % MSM_SLICE_POINTS ? n % MSM_SLICE_POINTS : cap}) {
+        const ptau::MsmPlan pl = msm_plan(std::max<uint64_t>(m, 1), scalar_bits);
+        wb_max = std::max(wb_max, (size_t)pl.W * pl.B);
+        w_max = std::max(w_max, (size_t)pl.W);
+    }
+    (void)big;
+    const size_t sz_aff = al((cap + 1) * ops->affine_bytes), sz_dig = al(w_max * cap * 4), sz_sorted = sz_dig,
+                 sz_counts = al(wb_max * 4), sz_offsets = al((wb_max + 1) * 4), sz_buckets = al(nsum * wb_max * ops->jac_bytes),
+                 sz_parts = sz_buckets, sz_totals = al((nsum * (nslice + 1) + 8) * ops->jac_bytes),
+                 sz_runs = al((wb_max + w_max * cap / ptau::MSM_RUN + 1) * ops->jac_bytes);   // <= one run per bucket + one per MSM_RUN entries
+    int rc;
+    if ((rc = grow(c->msm_ws, c->msm_cap, sz_aff + sz_dig + sz_sorted + sz_counts + 2 * sz_offsets + sz_buckets + sz_parts + sz_totals + sz_runs, err)))
+        return rc;
+    if ((rc = grow(c->pre, c->pre_cap, 16 * ops->fe_bytes, err))) return rc;
+    uint8_t *w8 = (uint8_t *)c->msm_ws;
+    void *aff = w8;                                   w8 += sz_aff;
+    uint32_t *dig = (uint32_t *)w8;                   w8 += sz_dig;
+    uint32_t *sorted = (uint32_t *)w8;                w8 += sz_sorted;
+    uint32_t *counts = (uint32_t *)w8;                w8 += sz_counts;
+    uint32_t *offsets = (uint32_t *)w8;               w8 += sz_offsets;
+    uint32_t *run_offsets = (uint32_t *)w8;           w8 += sz_offsets;
+    uint8_t *buckets = w8;                            w8 += sz_buckets;
+    uint8_t *parts = w8;                              w8 += sz_parts;
+    uint8_t *totals = w8;                             w8 += sz_totals;   // [sum][slice] Jacobians, then the final [sum]
+    uint8_t *runs = w8;                               // run partials of the accumulate pass
+    HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
+    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    uint64_t li = 0;
+    for (uint64_t off = 0; off < n || (n == 0 && li == 0); off += MSM_SLICE_POINTS, li++) {
+        const uint64_t m = std::min(MSM_SLICE_POINTS, n - off);
+        const ptau::MsmPlan pl = msm_plan(std::max<uint64_t>(m, 1), scalar_bits);
+        const uint64_t wb = (uint64_t)pl.W * pl.B;
+        ptau::ScalarSource s2 = src;
+        if (s2.mode == ptau::SCALAR_ARRAY) s2.ptr += off * ops->fr_limbs32;
+        s2.index_base += off;
+        HIP_TRY(hipMemsetAsync(counts, 0, wb * 4, c->stream));
+        ops->msm_prepare(c->stream, d_in + off * isz, cin, aff, dig, counts, m + (nsum - 1), m, s2, pl, c->d_err);
+        hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, c->stream, counts, offsets, run_offsets, (uint32_t)wb);
+        if (m) hipLaunchKernelGGL(ptau::msm_scatter_kernel<0>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, dig, counts, sorted, m, pl);
+        const uint64_t max_runs = wb + (uint64_t)pl.W * m / ptau::MSM_RUN + 1;
+        for (int sidx = 0; sidx < nsum; sidx++) {
+            ops->msm_accumulate(c->stream, aff, sorted, offsets, run_offsets, runs, (uint32_t)sidx, (uint32_t)wb, max_runs);
+            ops->msm_combine(c->stream, runs, run_offsets, buckets + (size_t)sidx * wb * ops->jac_bytes, wb);
+        }
+        // rows = nsum * W windows from here on
+        const uint32_t rows = (uint32_t)(nsum * pl.W);
+        uint32_t cols = pl.B / pl.seg;
+        ops->msm_bucket_reduce(c->stream, buckets, parts, pl, (uint64_t)rows * cols);
+        uint8_t *cur = parts, *nxt = buckets;   // ping-pong: the buckets are dead once reduced
+        while (cols > 1) {
+            const uint32_t T = (cols + 15) / 16;
+            ops->reduce_rows(c->stream, cur, nxt, rows, cols, T);
+            std::swap(cur, nxt);
+            cols = T;
+        }
+        for (int sidx = 0; sidx < nsum; sidx++)
+            ops->msm_horner(c->stream, cur + (size_t)sidx * pl.W * ops->jac_bytes, totals + ((size_t)sidx * nslice + li) * ops->jac_bytes, pl);
+    }
+    uint8_t *fin = totals + (size_t)nsum * nslice * ops->jac_bytes;
+    for (int sidx = 0; sidx < nsum; sidx++)
+        ops->reduce_sum(c->stream, totals + (size_t)sidx * nslice * ops->jac_bytes, fin + (size_t)sidx * ops->jac_bytes, li, 1);
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    ops->normalize(c->stream, fin, c->pre, (uint8_t *)c->d_small, cout, nsum, nsum, 0, c->d_err);
+    int bits = 0;
+    HIP_TRY(hipMemcpyAsync(&bits, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(out_a, c->d_small, osz, hipMemcpyDeviceToHost, c->stream));
+    if (out_b) HIP_TRY(hipMemcpyAsync(out_b, (uint8_t *)c->d_small + osz, osz, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    c->timing.kernel_ms += ms;
+    c->timing.msm_ms += ms;
+    c->timing.points += n * nsum;
+    return errbits_to_code(bits, err);
+}
+
+// Round-1 form of the same sum: n windowed scalar multiplications (the K1 kernel) followed by a tree of
+// Jacobian sums.  Kept for A/B measurements (PTAU_MSM=naive).  Caller holds the device mutex.
+int run_msm_naive_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, int cin, uint64_t n, ptau::ScalarSource src,
+                      uint8_t *out_host, int cout, const Err &err) {
     const int isz = cin ? ops->comp : ops->uncomp, osz = cout ? ops->comp : ops->uncomp;
     const uint64_t launch_cap =
         std::max<uint64_t>(256, std::min(MAX_LAUNCH_POINTS, MAX_WINDOW_TABLE_BYTES / (ptau::WINDOW_ENTRIES * ops->jac_bytes)));
@@ -261,9 +414,28 @@ int run_msm_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, int cin,
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
     c->timing.kernel_ms += ms;
-    c->timing.scalar_mul_ms += ms;
+    c->timing.msm_ms += ms;
     c->timing.points += n;
     return errbits_to_code(bits, err);
+}
+
+
+int run_msm_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, int cin, uint64_t n, ptau::ScalarSource src,
+                uint8_t *out_a, uint8_t *out_b, int cout, const Err &err) {
+    if (use_bucket_msm()) return run_msm_bucket_dev(c, ops, d_in, cin, n, src, out_a, out_b, cout, err);
+    const int isz = cin ? ops->comp : ops->uncomp;
+    int rc = run_msm_naive_dev(c, ops, d_in, cin, n, src, out_a, cout, err);
+    if (rc || !out_b) return rc;
+    return run_msm_naive_dev(c, ops, d_in + isz, cin, n, src, out_b, cout, err);
+}
+
+// PTAU_SUBGROUP=direct forces the [r]P == O form on every curve (A/B runs; the accept/reject set is the same).
+bool use_endo_subgroup() {
+    static const bool v = [] {
+        const char *e = getenv("PTAU_SUBGROUP");
+        return !(e && strcmp(e, "direct") == 0);
+    }();
+    return v;
 }
 
 bool cofactor_is_one(int curve, int group) {
@@ -282,8 +454,12 @@ int run_subgroup_check_dev(DeviceCtx *c, int curve, int group, const GroupOps *o
     HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_table, ops->group_order, sizeof(uint32_t) * ops->fr_limbs32, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-    if (!cin) ops->on_curve(c->stream, d_in, n, c->d_err);
-    if (!cofactor_is_one(curve, group)) {
+    if (ops->endo_subgroup && use_endo_subgroup()) {
+        ops->endo_subgroup(c->stream, d_in, cin, n, c->d_err);   // on-curve test included
+    } else if (!cin) {
+        ops->on_curve(c->stream, d_in, n, c->d_err);
+    }
+    if (!(ops->endo_subgroup && use_endo_subgroup()) && !cofactor_is_one(curve, group)) {
         for (uint64_t off = 0; off < n; off += launch_cap) {
             const uint64_t m = std::min(launch_cap, n - off);
             int rc;
@@ -302,7 +478,7 @@ int run_subgroup_check_dev(DeviceCtx *c, int curve, int group, const GroupOps *o
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
     c->timing.kernel_ms += ms;
-    c->timing.scalar_mul_ms += ms;
+    c->timing.subgroup_ms += ms;
     c->timing.points += n;
     return errbits_to_code(bits, err);
 }
@@ -332,15 +508,14 @@ int run_verify_vector(DeviceCtx *c, int curve, int group, const GroupOps *ops, c
     c->timing.h2d_ms += ms;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[4], c->ev[5]));
     c->timing.kernel_ms += ms;
-    c->timing.normalize_ms += ms;   // decompress time is reported in this slot for the verify path
+    c->timing.decompress_ms += ms;
     if ((rc = errbits_to_code(bits, err))) return rc;
     const bool want_subgroup = subgroup_check_mode != PTAU_SUBGROUP_NO || check_output == PTAU_CHECK_ONLY_IN_GROUP ||
                                check_output == PTAU_CHECK_FULL;
     if (want_subgroup && (rc = run_subgroup_check_dev(c, curve, group, ops, (const uint8_t *)c->d_out, 0, n, err))) return rc;
     if (ratio_seed && n >= 2) {   // power_pairs on the vector while it is still resident in HBM
         const ptau::ScalarSource src{ptau::SCALAR_PRF, nullptr, ratio_seed[0], ratio_seed[1], index_base};
-        if ((rc = run_msm_dev(c, ops, (const uint8_t *)c->d_out, 0, n - 1, src, pair_a, 0, err))) return rc;
-        if ((rc = run_msm_dev(c, ops, (const uint8_t *)c->d_out + ops->uncomp, 0, n - 1, src, pair_b, 0, err))) return rc;
+        if ((rc = run_msm_dev(c, ops, (const uint8_t *)c->d_out, 0, n - 1, src, pair_a, pair_b, 0, err))) return rc;
     }
     HIP_TRY(hipEventRecord(c->ev[3], c->stream));
     HIP_TRY(hipMemcpyAsync(out, c->d_out, n * ops->uncomp, hipMemcpyDeviceToHost, c->stream));
@@ -881,7 +1056,7 @@ int ptau_msm(int curve, int group, const uint8_t *in, int compressed_in, uint64_
         HIP_TRY(hipMemcpyAsync(d_pts, in, n * isz, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(d_k, k32.data(), k32.size() * 4, hipMemcpyHostToDevice, c->stream));
     }
-    return run_msm_dev(c, ops, d_pts, compressed_in, n, ptau::ScalarSource{ptau::SCALAR_ARRAY, d_k, 0, 0, 0}, out, compressed_out, err);
+    return run_msm_dev(c, ops, d_pts, compressed_in, n, ptau::ScalarSource{ptau::SCALAR_ARRAY, d_k, 0, 0, 0}, out, nullptr, compressed_out, err);
 }
 
 int ptau_power_pairs(int curve, int group, const uint8_t *in, int compressed_in, uint64_t n, const uint8_t seed[16],
@@ -913,8 +1088,7 @@ int ptau_power_pairs(int curve, int group, const uint8_t *in, int compressed_in,
     HIP_TRY(hipMemcpyAsync(c->d_in, in, n * isz, hipMemcpyHostToDevice, c->stream));
     const ptau::ScalarSource src{ptau::SCALAR_PRF, nullptr, s[0], s[1], index_base};
     // (sum rho_i P_i, sum rho_i P_{i+1}), i in [0, n-1): the same coefficients on the vector and on its shift
-    if ((rc = run_msm_dev(c, ops, (const uint8_t *)c->d_in, compressed_in, n - 1, src, out_a, 0, err))) return rc;
-    return run_msm_dev(c, ops, (const uint8_t *)c->d_in + isz, compressed_in, n - 1, src, out_b, 0, err);
+    return run_msm_dev(c, ops, (const uint8_t *)c->d_in, compressed_in, n - 1, src, out_a, out_b, 0, err);
 }
 
 int ptau_check_same_ratio(int curve, const uint8_t *g1_a, const uint8_t *g1_b, const uint8_t *g2_c, const uint8_t *g2_d,

@@ -74,16 +74,15 @@ struct Fp2 {
         F norm = F::sub(F::sqr(a.c0), F::mul_small(F::sqr(a.c1), NR));
         F alpha;
         if (!F::sqrt(norm, alpha)) return false;
-        // two_inv = 1/2
-        F two_inv = F::inverse(F::dbl(F::one()));
+        F two_inv = F::from_canonical(F::Params::QP1H);   // (p+1)/2 = 1/2
         F delta = F::mul(F::add(a.c0, alpha), two_inv);
-        F x0;
-        if (!F::sqrt(delta, x0)) {
+        F x0, x0_inv;
+        if (!F::sqrt_ex(delta, x0, &x0_inv)) {
             delta = F::mul(F::sub(a.c0, alpha), two_inv);
-            if (!F::sqrt(delta, x0)) return false;
+            if (!F::sqrt_ex(delta, x0, &x0_inv)) return false;
         }
         if (x0.is_zero()) return false;
-        F x1 = F::mul(F::mul(a.c1, two_inv), F::inverse(x0));
+        F x1 = F::mul(F::mul(a.c1, two_inv), x0_inv);
         out = {x0, x1};
         return sqr(out) == a;
     }

@@ -340,31 +340,46 @@ struct Fp {
         return br != 0;
     }
 
-    // Tonelli-Shanks square root; returns false when a is a non-residue.
-    __host__ __device__ __noinline__ static bool sqrt(const Fp &a, Fp &out) {
-        if (a.is_zero()) { out = zero(); return true; }
-        Fp x = pow_limbs(a, P::TS_T1H, P::BITS - 1);
-        Fp b = pow_limbs(a, P::TS_T, P::BITS - 1);
-        Fp c;
-#pragma unroll
-        for (int i = 0; i < N; i++) c.l[i] = P::TS_C[i];
-        const Fp o = one();
-        int m = P::TS_S;
-        while (b != o) {
-            int i = 0;
-            Fp b2 = b;
-            while (b2 != o && i < m) { b2 = sqr(b2); i++; }
-            if (i >= m) return false;   // non-residue
-            Fp e = c;
-            for (int k = 0; k < m - i - 1; k++) e = sqr(e);
-            x = mul(x, e);
-            c = sqr(e);
-            b = mul(b, c);
-            m = i;
+    // Square root; returns false when a is a non-residue.  p - 1 = 2^S T:
+    //   w = a^((T-1)/2) (the one exponentiation), x = a w = a^((T+1)/2), b = x w = a^T, so x^2 = a b and b lies in
+    //   the 2^S-torsion <g>.  For a residue b = (g^2)^d, d < 2^(S-1); d is recovered W bits at a time from the
+    //   bottom (Pohlig-Hellman: raise to 2^(E-Wj-w_j), look the order-2^W element up, strip the window with a
+    //   tabulated power of g) and sqrt(a) = x g^(-d).  About S^2/(2W) squarings with wave-uniform control flow,
+    //   against ~S^2/4 and heavy divergence for the Tonelli-Shanks loop (S = 46 for BLS12-377 Fq).
+    // inv_out (optional) receives 1/sqrt(a) = sqrt(a) (w g^(-d))^2 for three more products: a^(-1) = a^(T-1) b^(-1).
+    __host__ __device__ __noinline__ static bool sqrt_ex(const Fp &a, Fp &out, Fp *inv_out) {
+        if (a.is_zero()) {
+            out = zero();
+            if (inv_out) *inv_out = zero();
+            return true;
         }
-        out = x;
+        const Fp w = pow_limbs(a, P::TS_TM1H, P::TS_TM1H_BITS - 1);
+        const Fp x = mul(a, w);
+        Fp b = mul(x, w);
+        Fp gd = one();
+        constexpr int E = P::TS_S - 1, W = P::SQRT_W;
+        for (int j = 0; j < P::SQRT_L; j++) {
+            const int wj = (E - W * j) < W ? (E - W * j) : W;
+            const int sh = E - W * j - wj;
+            Fp t = b;
+            for (int k = 0; k < sh; k++) t = sqr(t);
+            const uint32_t lo = t.l[0];
+            int K = -1;
+            for (int k = 0; k < (1 << W); k++) K = (P::SQRT_ZLOW[k] == lo) ? k : K;   // uniform table, scalar loads
+            if (K < 0) return false;   // a^T outside <g^2>: non-residue
+            const int d = K >> (W - wj);
+            Fp f;
+#pragma unroll
+            for (int i = 0; i < N; i++) f.l[i] = P::SQRT_GNEG[(j << W) + d][i];
+            gd = mul(gd, f);
+            b = mul(b, sqr(f));
+        }
+        out = mul(x, gd);
+        if (sqr(out) != a) return false;
+        if (inv_out) *inv_out = mul(out, sqr(mul(w, gd)));
         return true;
     }
+    PTAU_HD static bool sqrt(const Fp &a, Fp &out) { return sqrt_ex(a, out, nullptr); }
 
     // ---- canonical little-endian bytes (arkworks serialize) ----
     // Reads BYTES bytes; *flags receives the top two bits of the last byte when with_flags.

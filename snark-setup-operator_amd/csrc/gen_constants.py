@@ -27,7 +27,7 @@ def limbs(x, n):
     return ", ".join("0x%08xu" % ((x >> (32 * i)) & 0xFFFFFFFF) for i in range(n))
 
 
-def field(name, p, cubic_nr=None):
+def field(name, p, cubic_nr=None, sqrt_tables=False):
     n = (p.bit_length() + 31) // 32
     R = 1 << (32 * n)
     inv = (-pow(p, -1, 1 << 32)) % (1 << 32)
@@ -53,6 +53,37 @@ def field(name, p, cubic_nr=None):
     s.append("  static constexpr uint32_t TS_T1H[%d] = {%s};    // (T+1)/2" % (n, limbs((T + 1) // 2, n)))
     s.append("  static constexpr uint32_t TS_C[%d] = {%s};      // nonresidue^T (Montgomery)" % (n, limbs(pow(z, T, p) * R % p, n)))
     s.append("  static constexpr uint32_t QP1H[%d] = {%s};      // (p+1)/2" % (n, limbs((p + 1) // 2, n)))
+    s.append("  static constexpr uint32_t TS_TM1H[%d] = {%s};   // (T-1)/2" % (n, limbs((T - 1) // 2, n)))
+    s.append("  static constexpr int TS_TM1H_BITS = %d;" % max(1, ((T - 1) // 2).bit_length()))
+    if sqrt_tables:
+        # Pohlig-Hellman data for the 2-Sylow part of the square root (fp.hpp sqrt_ex): g = z^T generates the
+        # 2^S-torsion; a residue has a^T = (g^2)^d with d < 2^E, E = S-1, found W bits at a time from the bottom.
+        #   SQRT_ZLOW[k]     = low Montgomery limb of zeta^k, zeta = (g^2)^(2^(E-W)) of order 2^W (lookup key)
+        #   SQRT_GNEG[j][k]  = g^(-k 2^(W j)), Montgomery: strips window j from the residue and builds g^(-d)
+        E = S - 1
+        W = min(6, E) if E > 0 else 0
+        L = (E + W - 1) // W if W else 0
+        g = pow(z, T, p)
+        s.append("  static constexpr int SQRT_W = %d;" % W)
+        s.append("  static constexpr int SQRT_L = %d;" % L)
+        if W:
+            h = g * g % p
+            zeta = pow(h, 1 << (E - W), p)
+            zl = [pow(zeta, k, p) * R % p & 0xFFFFFFFF for k in range(1 << W)]
+            assert len(set(zl)) == len(zl), "low-limb collision in the sqrt lookup table"
+            s.append("  static constexpr uint32_t SQRT_ZLOW[%d] = {%s};" % (1 << W, ", ".join("0x%08xu" % v for v in zl)))
+            ginv = pow(g, -1, p)
+            rows = []
+            for j in range(L):
+                base = pow(ginv, 1 << (W * j), p)
+                acc = 1
+                for k in range(1 << W):
+                    rows.append("{%s}" % limbs(acc * R % p, n))
+                    acc = acc * base % p
+            s.append("  static constexpr uint32_t SQRT_GNEG[%d][%d] = {%s};" % (L << W, n, ",\n    ".join(rows)))
+        else:
+            s.append("  static constexpr uint32_t SQRT_ZLOW[1] = {0};")
+            s.append("  static constexpr uint32_t SQRT_GNEG[1][%d] = {{0}};" % n)
     if cubic_nr is not None:
         # Frobenius on Fq[u]/(u^3 - nr): (a0, a1, a2)^q = (a0, a1*c1, a2*c1^2), c1 = nr^((q-1)/3)
         c1 = pow(cubic_nr, (p - 1) // 3, p)
@@ -70,17 +101,25 @@ def main():
     out = ["// GENERATED by gen_constants.py — do not edit.", "#pragma once", "#include <cstdint>", "namespace ptau {"]
     fields = {}
     for name, p in (("BlsFq", BLS_Q), ("BlsFr", BLS_R), ("Bw6Fq", BW6_Q), ("Mnt4Fq", MNT_A), ("Mnt6Fq", MNT_B)):
-        txt, n, R = field(name, p, cubic_nr=11 if name == "Mnt6Fq" else None)
+        txt, n, R = field(name, p, cubic_nr=11 if name == "Mnt6Fq" else None, sqrt_tables=name.endswith("Fq"))
         fields[name] = (p, n, R)
         out.append(txt)
     out.append("using Bw6Fr = BlsFq;")
     out.append("using Mnt4Fr = Mnt6Fq;")
     out.append("using Mnt6Fr = Mnt4Fq;")
 
-    def coeffs(cname, fname, deg, a, b, nr, glv=None):
+    def coeffs(cname, fname, deg, a, b, nr, glv=None, endo=None):
         p, n, R = fields[fname]
         s = ["struct %s {" % cname]
         s.append("  static constexpr bool HAS_GLV = %s;" % ("true" if glv else "false"))
+        # endomorphism-based subgroup membership test (eprint 2021/1130):
+        #   kind 1 (BLS12 G1): P in G1  <=>  (C0 x, y) == -[X^2] P          (C0 = the cube root of unity acting as -X^2)
+        #   kind 2 (BLS12 G2): P in G2  <=>  (C0 conj(x), C1 conj(y)) == [X] P   (untwist-Frobenius-twist, C0, C1 in Fq)
+        s.append("  static constexpr int ENDO_KIND = %d;" % (endo[0] if endo else 0))
+        if endo:
+            s.append("  static constexpr uint64_t ENDO_X = 0x%xull;" % endo[1])
+            s.append("  static constexpr uint32_t ENDO_C0[%d] = {%s};" % (n, limbs(endo[2] * R % p, n)))
+            s.append("  static constexpr uint32_t ENDO_C1[%d] = {%s};" % (n, limbs(endo[3] * R % p, n)))
         if glv:
             # phi(x, y) = (BETA x, y) = LAMBDA * (x, y) on the prime-order subgroup; k = k1 + k2*LAMBDA with
             # k2 = floor(k / LAMBDA), both below 2^127.  GLV_M = floor(2^256 / LAMBDA) for the reciprocal division.
@@ -105,8 +144,23 @@ def main():
     while pow(g, (BLS_Q - 1) // 3, BLS_Q) == 1:
         g += 1
     bls_beta = pow(g, 2 * (BLS_Q - 1) // 3, BLS_Q)   # the cube root of unity matching lambda = x^2 - 1 (tests check phi(G) = lambda G)
-    out.append(coeffs("BlsG1Cfg", "BlsFq", 1, (0,), (1,), 0, glv=(bls_beta, bls_lambda)))
-    out.append(coeffs("BlsG2Cfg", "BlsFq", 2, (0, 0), (0, BLS_G2_B1), -5))
+    # lambda^2 = -x^2 mod r is the eigenvalue of beta^2: the G1 membership test compares (beta^2 x, y) with -[x^2]P
+    assert (bls_lambda * bls_lambda + bls_x * bls_x) % BLS_R == 0
+    out.append(coeffs("BlsG1Cfg", "BlsFq", 1, (0,), (1,), 0, glv=(bls_beta, bls_lambda),
+                      endo=(1, bls_x, bls_beta * bls_beta % BLS_Q, 0)))
+    # psi(x, y) = (xi^((q-1)/3) conj(x), xi^((q-1)/2) conj(y)), xi = u (D-type twist, b' = b/xi); both constants lie in Fq.
+    # Sound because q - x = r (x-1)^2/3 and gcd((x-1)^2/3, #E'(Fq2)/r) = 1 (checked in tests/test_oracle.py).
+    def fq2_pow_u(e):   # u^e in Fq[u]/(u^2 + 5)
+        r0, r1, b0, b1 = 1, 0, 0, 1
+        while e:
+            if e & 1:
+                r0, r1 = (r0 * b0 - 5 * r1 * b1) % BLS_Q, (r0 * b1 + r1 * b0) % BLS_Q
+            b0, b1 = (b0 * b0 - 5 * b1 * b1) % BLS_Q, 2 * b0 * b1 % BLS_Q
+            e >>= 1
+        return r0, r1
+    psi_cx, psi_cy = fq2_pow_u((BLS_Q - 1) // 3), fq2_pow_u((BLS_Q - 1) // 2)
+    assert psi_cx[1] == 0 and psi_cy[1] == 0
+    out.append(coeffs("BlsG2Cfg", "BlsFq", 2, (0, 0), (0, BLS_G2_B1), -5, endo=(2, bls_x, psi_cx[0], psi_cy[0])))
     out.append(coeffs("Bw6G1Cfg", "Bw6Fq", 1, (0,), (BW6_Q - 1,), 0))
     out.append(coeffs("Bw6G2Cfg", "Bw6Fq", 1, (0,), (4,), 0))
     out.append(coeffs("Mnt4G1Cfg", "Mnt4Fq", 1, (2,), (MNT4_B1,), 0))

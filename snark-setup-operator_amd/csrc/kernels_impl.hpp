@@ -133,10 +133,36 @@ PTAU_HD uint64_t splitmix64(uint64_t z) {
 }
 // word j of the random coefficient rho_idx of merge_pairs / power_pairs (setup-utils draws Fr::rand from
 // thread_rng; here a counter-based generator keyed by a per-verification 128-bit secret, so that any slice
-// of a vector, on any GPU, sees the same rho for the same global index).  rho < 2^(BITS-1) < r.
+// of a vector, on any GPU, sees the same rho for the same global index).  rho = words 0..3, top bit cleared (PRF_BITS = 127).
 PTAU_HD uint32_t prf_word(uint64_t seed0, uint64_t seed1, uint64_t idx, int nl, int j) {
     uint64_t z = splitmix64(seed0 + (idx * (uint64_t)nl + (uint64_t)j + 1) * 0x9E3779B97F4A7C15ull) ^ seed1;
     return (uint32_t)(splitmix64(z) >> 32);
+}
+
+// Number of random bits in a power_pairs coefficient.  setup-utils draws full-width Fr::rand; the check
+// sum_i rho_i (v_{i+1} - tau v_i) == O is equally sound with 127-bit rho (a cheating vector passes with
+// probability 2^-127: distinct 127-bit values stay distinct mod r > 2^252), and the MSM is half as long.
+constexpr int PRF_BITS = 127;   // + the sign-recoding carry = 128 = 8 full windows of 16 bits at 2^20 points
+
+// The scalar of element i under a ScalarSource, as NL canonical 32-bit limbs.
+template <class Fr>
+PTAU_HD void thread_scalar(const ScalarSource &src, uint64_t i, uint32_t (&k)[Fr::N]) {
+    constexpr int NL = Fr::N;
+    if (src.mode == SCALAR_FIXED) {          // one public scalar for every point (subgroup check: the group order)
+#pragma unroll
+        for (int j = 0; j < NL; j++) k[j] = src.ptr[j];
+    } else if (src.mode == SCALAR_ARRAY) {   // explicit per-point scalars (MSM with caller-supplied coefficients)
+#pragma unroll
+        for (int j = 0; j < NL; j++) k[j] = src.ptr[i * NL + j];
+    } else if (src.mode == SCALAR_PRF) {     // random linear combination coefficients
+        static_assert(NL * 32 >= PRF_BITS && Fr::Params::BITS > PRF_BITS, "scalar field too small for the PRF width");
+#pragma unroll
+        for (int j = 0; j < NL; j++) k[j] = j < 4 ? prf_word(src.seed0, src.seed1, src.index_base + i, NL, j) : 0u;
+        k[3] &= 0x7fffffffu;
+    } else {
+        Fr ek = scalar_for_index<Fr>(src.ptr, i);
+        ek.to_canonical(k);
+    }
 }
 
 // GLV decomposition for curves with the endomorphism phi(x, y) = (beta x, y) (BLS12-377 G1):
@@ -231,21 +257,7 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
         wtab[(uint64_t)e * n + i] = cur;
     }
     uint32_t k[NL];
-    if (src.mode == SCALAR_FIXED) {          // one public scalar for every point (subgroup check: the group order)
-#pragma unroll
-        for (int j = 0; j < NL; j++) k[j] = src.ptr[j];
-    } else if (src.mode == SCALAR_ARRAY) {   // explicit per-point scalars (MSM with caller-supplied coefficients)
-#pragma unroll
-        for (int j = 0; j < NL; j++) k[j] = src.ptr[i * NL + j];
-    } else if (src.mode == SCALAR_PRF) {     // random linear combination coefficients
-        constexpr int TOPBITS = (Fr::Params::BITS - 1) - 32 * (NL - 1);   // bits kept in the top limb
-#pragma unroll
-        for (int j = 0; j < NL; j++) k[j] = prf_word(src.seed0, src.seed1, src.index_base + i, NL, j);
-        k[NL - 1] &= (TOPBITS >= 32) ? 0xffffffffu : ((1u << TOPBITS) - 1u);
-    } else {
-        Fr ek = scalar_for_index<Fr>(src.ptr, i);
-        ek.to_canonical(k);
-    }
+    thread_scalar<Fr>(src, i, k);
     using Cfg = typename J::CfgT;
     if constexpr (Cfg::HAS_GLV && NL == 8) {
         if (use_glv) {
@@ -337,6 +349,231 @@ reduce_sum_kernel(const typename G::J *__restrict__ in, typename G::J *__restric
     reduce_sum_thread<G>(in, out, n, T, t);
 }
 
+// ---- K4: multi-scalar multiplication, bucket method ------------------------------------------------------
+// Replaces setup-utils' dense_multiexp / merge_pairs / power_pairs (bellman-style Pippenger on the CPU;
+// reference call sites /root/reference/src/bin/verify_transcript.rs:812-822, src/bin/control.rs:587-591).
+//   msm_prepare    : thread i converts point i to Montgomery affine ONCE, cuts its scalar into W signed c-bit
+//                    digits d in [-2^(c-1), 2^(c-1)] and counts the bucket (w, |d|) it will land in;
+//   exclusive scan : bucket counts -> offsets (capi.hip, one workgroup);
+//   msm_scatter    : counting sort of the point indices by (window, bucket);
+//   msm_accumulate / msm_combine : bucket sums by mixed additions (P_i, or P_{i+1} for the shifted sum of
+//                    power_pairs — both sums share digits, sort and the affine array), a bucket cut into runs
+//                    of <= MSM_RUN entries so that a crowded bucket is still summed in parallel;
+//   msm_bucket_reduce : per window sum_b b * bucket[b] by running sums over segments of SEG buckets;
+//   reduce_rows, msm_horner : segment partials -> window sums -> sum_w 2^(c w) R_w.
+// Every sum is over group elements, so the affine result is canonical whatever the addition order.
+struct MsmPlan {
+    int c;            // window bits
+    int W;            // windows: W * c >= scalar bits + 1 (the signed recoding carries one bit up)
+    uint32_t B;       // buckets per window = 2^(c-1)
+    uint32_t seg;     // buckets per bucket-reduce thread
+};
+
+PTAU_HD uint32_t atomic_inc_u32(uint32_t *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return atomicAdd(p, 1u);
+#else
+    return (*p)++;
+#endif
+}
+
+// digit entry: 0 = nothing to add; else bit 31 = negative, low bits = magnitude in [1, 2^(c-1)]
+template <class G>
+PTAU_HD int msm_prepare_thread(const uint8_t *in, int compressed_in, typename G::A *aff, uint32_t *dig,
+                               uint32_t *counts, uint64_t n_points, uint64_t n_scalars, uint64_t i,
+                               const ScalarSource &src, const MsmPlan &pl) {
+    using Fr = typename G::Fr;
+    using F = typename G::F;
+    constexpr int NL = Fr::N;
+    typename G::A p;
+    int bad = read_point_any<G>(in, compressed_in, i, p);
+    if (bad) p.inf = true;
+    if (p.inf) { p.x = F::zero(); p.y = F::zero(); }
+    aff[i] = p;
+    if (i >= n_scalars) return bad;
+    uint32_t k[NL];
+    thread_scalar<Fr>(src, i, k);
+    const uint32_t mask = (1u << pl.c) - 1u;
+    uint32_t carry = 0;
+    for (int w = 0; w < pl.W; w++) {
+        const int bit = w * pl.c, li = bit >> 5, sh = bit & 31;
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int j = 0; j < NL; j++) {   // register select, no scratch
+            lo = (j == li) ? k[j] : lo;
+            hi = (j == li + 1) ? k[j] : hi;
+        }
+        uint32_t v = (uint32_t)((((uint64_t)hi << 32) | lo) >> sh) & mask;
+        v += carry;
+        uint32_t e = 0;
+        if (v > pl.B) {            // negative digit v - 2^c, carry one into the next window
+            v = (1u << pl.c) - v;
+            carry = 1;
+            if (v) e = v | 0x80000000u;
+        } else {
+            carry = 0;
+            if (v) e = v;
+        }
+        dig[(uint64_t)w * n_scalars + i] = e;
+        if (e) atomic_inc_u32(&counts[(uint64_t)w * pl.B + (e & 0x7fffffffu) - 1]);
+    }
+    return bad;
+}
+template <class G>
+__global__ void __launch_bounds__(256)
+msm_prepare_kernel(const uint8_t *__restrict__ in, int compressed_in, typename G::A *__restrict__ aff,
+                   uint32_t *__restrict__ dig, uint32_t *__restrict__ counts, uint64_t n_points, uint64_t n_scalars,
+                   ScalarSource src, MsmPlan pl, int *__restrict__ err) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_points) return;
+    int bad = msm_prepare_thread<G>(in, compressed_in, aff, dig, counts, n_points, n_scalars, i, src, pl);
+    if (bad) atomicOr(err, bad);
+}
+
+PTAU_HD void msm_scatter_thread(const uint32_t *dig, uint32_t *cursor, uint32_t *sorted, uint64_t n, uint64_t i,
+                                const MsmPlan &pl) {
+    for (int w = 0; w < pl.W; w++) {
+        const uint32_t e = dig[(uint64_t)w * n + i];
+        if (!e) continue;
+        const uint32_t pos = atomic_inc_u32(&cursor[(uint64_t)w * pl.B + (e & 0x7fffffffu) - 1]);
+        sorted[pos] = (uint32_t)i | (e & 0x80000000u);
+    }
+}
+
+template <int DUMMY>
+__global__ void __launch_bounds__(256)
+msm_scatter_kernel(const uint32_t *__restrict__ dig, uint32_t *__restrict__ cursor, uint32_t *__restrict__ sorted,
+                   uint64_t n, MsmPlan pl) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    msm_scatter_thread(dig, cursor, sorted, n, i, pl);
+}
+
+// Bucket sums in two steps so that one crowded bucket (a skewed scalar distribution, a short top window) cannot
+// serialise the pass: bucket b is cut into ceil(count_b / MSM_RUN) runs of at most MSM_RUN sorted entries;
+//   msm_accumulate : one thread per RUN — finds its bucket by bisection of the run offsets, adds +-P over its entries
+//                    (shift = 1 adds P_{i+1} instead of P_i: the shifted sum of power_pairs);
+//   msm_combine    : one thread per bucket — sums the bucket's run partials (one or two for a balanced window).
+constexpr uint32_t MSM_RUN = 64;
+
+template <class G>
+PTAU_HD void msm_accumulate_thread(const typename G::A *aff, const uint32_t *sorted, const uint32_t *offsets,
+                                   const uint32_t *run_offsets, typename G::J *partials, uint32_t shift,
+                                   uint32_t total_buckets, uint32_t v) {
+    using J = typename G::J;
+    using F = typename G::F;
+    uint32_t lo = 0, hi = total_buckets;   // largest b with run_offsets[b] <= v  (run_offsets[total_buckets] > v)
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (run_offsets[mid] <= v) lo = mid; else hi = mid;
+    }
+    const uint32_t b = lo;
+    const uint32_t e0 = offsets[b] + (v - run_offsets[b]) * MSM_RUN;
+    const uint32_t bend = offsets[b + 1];
+    const uint32_t e1 = e0 + MSM_RUN < bend ? e0 + MSM_RUN : bend;
+    J acc = J::infinity();
+    for (uint32_t e = e0; e < e1; e++) {
+        const uint32_t s = sorted[e];
+        typename G::A q = aff[(uint64_t)(s & 0x7fffffffu) + shift];
+        if (s >> 31) q.y = F::neg(q.y);
+        acc = J::add_mixed(acc, q);
+    }
+    partials[v] = acc;
+}
+template <class G>
+__global__ void __launch_bounds__(256)
+msm_accumulate_kernel(const typename G::A *__restrict__ aff, const uint32_t *__restrict__ sorted,
+                      const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ run_offsets,
+                      typename G::J *__restrict__ partials, uint32_t shift, uint32_t total_buckets) {
+    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= run_offsets[total_buckets]) return;   // the grid is sized for the worst case, the run count lives on the device
+    msm_accumulate_thread<G>(aff, sorted, offsets, run_offsets, partials, shift, total_buckets, (uint32_t)v);
+}
+
+template <class G>
+PTAU_HD void msm_combine_thread(const typename G::J *partials, const uint32_t *run_offsets, typename G::J *buckets, uint64_t t) {
+    using J = typename G::J;
+    J acc = J::infinity();
+    const uint32_t v1 = run_offsets[t + 1];
+    for (uint32_t v = run_offsets[t]; v < v1; v++) acc = J::add(acc, partials[v]);
+    buckets[t] = acc;
+}
+template <class G>
+__global__ void __launch_bounds__(256)
+msm_combine_kernel(const typename G::J *__restrict__ partials, const uint32_t *__restrict__ run_offsets,
+                   typename G::J *__restrict__ buckets, uint64_t total_buckets) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total_buckets) return;
+    msm_combine_thread<G>(partials, run_offsets, buckets, t);
+}
+
+// thread (w, s): sum_{b in segment s} (b + 1) * bucket[w][b]  =  sum of running sums + lo * (segment sum)
+template <class G>
+PTAU_HD void msm_bucket_reduce_thread(const typename G::J *buckets, typename G::J *parts, const MsmPlan &pl, uint64_t t) {
+    using J = typename G::J;
+    const uint32_t nseg = pl.B / pl.seg;
+    const uint32_t w = (uint32_t)(t / nseg), sg = (uint32_t)(t % nseg), lo = sg * pl.seg;
+    const J *bw = buckets + (uint64_t)w * pl.B;
+    J run = J::infinity(), tot = J::infinity();
+    for (uint32_t b = lo + pl.seg; b-- > lo;) {
+        run = J::add(run, bw[b]);
+        tot = J::add(tot, run);
+    }
+    if (lo) {   // + lo * run, MSB-first double-and-add over the (<= 16) bits of lo
+        J acc = J::infinity();
+        for (int bit = 31 - __builtin_clz(lo); bit >= 0; bit--) {
+            acc = J::dbl(acc);
+            if ((lo >> bit) & 1u) acc = J::add(acc, run);
+        }
+        tot = J::add(tot, acc);
+    }
+    parts[t] = tot;
+}
+template <class G>
+__global__ void __launch_bounds__(256)
+msm_bucket_reduce_kernel(const typename G::J *__restrict__ buckets, typename G::J *__restrict__ parts, MsmPlan pl,
+                         uint64_t total) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    msm_bucket_reduce_thread<G>(buckets, parts, pl, t);
+}
+
+// rows x cols -> rows x T: thread (r, t) sums in[r][t], in[r][t + T], ...
+template <class G>
+PTAU_HD void reduce_rows_thread(const typename G::J *in, typename G::J *out, uint32_t cols, uint32_t T, uint64_t id) {
+    using J = typename G::J;
+    const uint64_t r = id / T, t = id % T;
+    J acc = J::infinity();
+    for (uint64_t j = t; j < cols; j += T) acc = J::add(acc, in[r * cols + j]);
+    out[id] = acc;
+}
+template <class G>
+__global__ void __launch_bounds__(256)
+reduce_rows_kernel(const typename G::J *__restrict__ in, typename G::J *__restrict__ out, uint32_t cols, uint32_t T,
+                   uint64_t total) {
+    uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= total) return;
+    reduce_rows_thread<G>(in, out, cols, T, id);
+}
+
+// sum_w 2^(c w) win[w]  (one thread: W*c doublings in sequence is inherent to the weighting)
+template <class G>
+PTAU_HD void msm_horner_thread(const typename G::J *win, typename G::J *out, const MsmPlan &pl) {
+    using J = typename G::J;
+    J acc = J::infinity();
+    for (int w = pl.W - 1; w >= 0; w--) {
+        if (!acc.is_inf())
+            for (int d = 0; d < pl.c; d++) acc = J::dbl(acc);
+        acc = J::add(acc, win[w]);
+    }
+    *out = acc;
+}
+template <class G>
+__global__ void __launch_bounds__(64)
+msm_horner_kernel(const typename G::J *__restrict__ win, typename G::J *__restrict__ out, MsmPlan pl) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) msm_horner_thread<G>(win, out, pl);
+}
+
 // y^2 == x^3 + a x + b for uncompressed inputs (compressed reads are on the curve by construction)
 template <class G>
 PTAU_HD int on_curve_thread(const uint8_t *in, uint64_t i) {
@@ -352,6 +589,60 @@ on_curve_kernel(const uint8_t *__restrict__ in, uint64_t n, int *__restrict__ er
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int bad = on_curve_thread<G>(in, i);
+    if (bad) atomicOr(err, bad);
+}
+
+// ---- K3': subgroup membership through an efficient endomorphism (BLS12-377) -------------------------------
+// Same accept/reject set as [r]P == O (setup-utils check_subgroup, SubgroupCheckMode::Direct), at 1/2 (G1) and
+// 1/4 (G2) of the doublings — eprint 2021/1130 (the test ark-bls12-377 0.4's is_in_correct_subgroup_assuming_on_curve
+// applies):   G1: (C0 x, y) == -[X^2] P        G2: psi(P) = (C0 conj(x), C1 conj(y)) == [X] P.
+// X = 0x8508c00000000001 has 7 set bits: plain MSB-first double-and-add, wave-uniform control flow, no table.
+template <class G>
+PTAU_HD int endo_subgroup_thread(const uint8_t *in, int compressed_in, uint64_t i) {
+    using F = typename G::F;
+    using B = typename F::Base;
+    using A = typename G::A;
+    using J = typename G::J;
+    using Cfg = typename J::CfgT;
+    static_assert(Cfg::ENDO_KIND == 1 || Cfg::ENDO_KIND == 2, "no endomorphism test for this group");
+    A p;
+    int bad = read_point_any<G>(in, compressed_in, i, p);
+    if (bad) return bad;
+    if (p.inf) return 0;
+    if (!compressed_in && !(F::sqr(p.y) == curve_rhs<F, Cfg>(p.x))) return ERRBIT_NOT_ON_CURVE;
+    constexpr uint64_t X = Cfg::ENDO_X;
+    J t = J::from_affine(p);
+    for (int b = 62; b >= 0; b--) {   // bit 63 of X is set
+        t = J::dbl(t);
+        if ((X >> b) & 1ull) t = J::add_mixed(t, p);
+    }
+    B c0, c1;
+#pragma unroll
+    for (int j = 0; j < B::N; j++) { c0.l[j] = Cfg::ENDO_C0[j]; c1.l[j] = Cfg::ENDO_C1[j]; }
+    F ex, ey;   // the endomorphism image (affine) the Jacobian multiple must equal
+    if constexpr (Cfg::ENDO_KIND == 1) {
+        const J base = t;
+        for (int b = 62; b >= 0; b--) {
+            t = J::dbl(t);
+            if ((X >> b) & 1ull) t = J::add(t, base);
+        }
+        ex = F::mul(p.x, c0);
+        ey = F::neg(p.y);
+    } else {
+        ex = F{B::mul(p.x.c0, c0), B::mul(B::neg(p.x.c1), c0)};
+        ey = F{B::mul(p.y.c0, c1), B::mul(B::neg(p.y.c1), c1)};
+    }
+    if (t.is_inf()) return ERRBIT_NOT_IN_SUBGROUP;
+    const F zz = F::sqr(t.Z);
+    const bool ok = (t.X == F::mul(ex, zz)) && (t.Y == F::mul(ey, F::mul(zz, t.Z)));
+    return ok ? 0 : ERRBIT_NOT_IN_SUBGROUP;
+}
+template <class G>
+__global__ void __launch_bounds__(256)
+endo_subgroup_kernel(const uint8_t *__restrict__ in, int compressed_in, uint64_t n, int *__restrict__ err) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int bad = endo_subgroup_thread<G>(in, compressed_in, i);
     if (bad) atomicOr(err, bad);
 }
 
@@ -484,12 +775,24 @@ struct GroupOps {
     void (*window_scalar_mul)(hipStream_t, const uint8_t *in, int cin, void *scratch, void *wtab, uint64_t n,
                               ScalarSource src, int check_input, int use_glv, int *err);
     void (*reduce_sum)(hipStream_t, const void *in, void *out, uint64_t n, uint64_t T);
+    // bucket MSM (K4)
+    size_t affine_bytes;
+    void (*msm_prepare)(hipStream_t, const uint8_t *in, int cin, void *aff, uint32_t *dig, uint32_t *counts, uint64_t n_points,
+                        uint64_t n_scalars, ScalarSource src, MsmPlan pl, int *err);
+    void (*msm_accumulate)(hipStream_t, const void *aff, const uint32_t *sorted, const uint32_t *offsets,
+                           const uint32_t *run_offsets, void *partials, uint32_t shift, uint32_t total_buckets, uint64_t max_runs);
+    void (*msm_combine)(hipStream_t, const void *partials, const uint32_t *run_offsets, void *buckets, uint64_t total_buckets);
+    void (*msm_bucket_reduce)(hipStream_t, const void *buckets, void *parts, MsmPlan pl, uint64_t total);
+    void (*reduce_rows)(hipStream_t, const void *in, void *out, uint32_t rows, uint32_t cols, uint32_t T);
+    void (*msm_horner)(hipStream_t, const void *win, void *out, MsmPlan pl);
     void (*on_curve)(hipStream_t, const uint8_t *in, uint64_t n, int *err);
     void (*fixed_scalar_mul)(hipStream_t, const uint8_t *in, int cin, void *scratch, uint64_t n,
                              const uint32_t *scalar, int nbits, int *err);
     void (*normalize)(hipStream_t, const void *scratch, void *pre, uint8_t *out, int cout, uint64_t n, uint64_t T,
                       int check_nonzero, int *err);
     void (*expect_infinity)(hipStream_t, const void *scratch, uint64_t n, int *err);
+    // endomorphism membership test incl. the on-curve test of uncompressed input; NULL where the group has none
+    void (*endo_subgroup)(hipStream_t, const uint8_t *in, int cin, uint64_t n, int *err);
     void (*decompress)(hipStream_t, const uint8_t *in, uint8_t *out, uint64_t n, int check_nonzero, int *err);
     const uint32_t *group_order;   // r, canonical 32-bit limbs (fr_limbs32)
     // O(1) host-side decompression for the pairing tail (a handful of public-key / head elements)
@@ -539,6 +842,33 @@ struct Launch {
         if (!T) return;
         hipLaunchKernelGGL(reduce_sum_kernel<G>, grid(T), dim3(256), 0, s, (const typename G::J *)in, (typename G::J *)out, n, T);
     }
+    static void msm_prepare(hipStream_t s, const uint8_t *in, int cin, void *aff, uint32_t *dig, uint32_t *counts,
+                            uint64_t n_points, uint64_t n_scalars, ScalarSource src, MsmPlan pl, int *err) {
+        if (!n_points) return;
+        hipLaunchKernelGGL(msm_prepare_kernel<G>, grid(n_points), dim3(256), 0, s, in, cin, (typename G::A *)aff, dig, counts,
+                           n_points, n_scalars, src, pl, err);
+    }
+    static void msm_accumulate(hipStream_t s, const void *aff, const uint32_t *sorted, const uint32_t *offsets,
+                               const uint32_t *run_offsets, void *partials, uint32_t shift, uint32_t total_buckets, uint64_t max_runs) {
+        hipLaunchKernelGGL(msm_accumulate_kernel<G>, grid(max_runs), dim3(256), 0, s, (const typename G::A *)aff, sorted,
+                           offsets, run_offsets, (typename G::J *)partials, shift, total_buckets);
+    }
+    static void msm_combine(hipStream_t s, const void *partials, const uint32_t *run_offsets, void *buckets, uint64_t total_buckets) {
+        hipLaunchKernelGGL(msm_combine_kernel<G>, grid(total_buckets), dim3(256), 0, s, (const typename G::J *)partials,
+                           run_offsets, (typename G::J *)buckets, total_buckets);
+    }
+    static void msm_bucket_reduce(hipStream_t s, const void *buckets, void *parts, MsmPlan pl, uint64_t total) {
+        hipLaunchKernelGGL(msm_bucket_reduce_kernel<G>, grid(total), dim3(256), 0, s, (const typename G::J *)buckets,
+                           (typename G::J *)parts, pl, total);
+    }
+    static void reduce_rows(hipStream_t s, const void *in, void *out, uint32_t rows, uint32_t cols, uint32_t T) {
+        const uint64_t total = (uint64_t)rows * T;
+        hipLaunchKernelGGL(reduce_rows_kernel<G>, grid(total), dim3(256), 0, s, (const typename G::J *)in, (typename G::J *)out,
+                           cols, T, total);
+    }
+    static void msm_horner(hipStream_t s, const void *win, void *out, MsmPlan pl) {
+        hipLaunchKernelGGL(msm_horner_kernel<G>, dim3(1), dim3(64), 0, s, (const typename G::J *)win, (typename G::J *)out, pl);
+    }
     static void on_curve(hipStream_t s, const uint8_t *in, uint64_t n, int *err) {
         if (!n) return;
         hipLaunchKernelGGL(on_curve_kernel<G>, grid(n), dim3(256), 0, s, in, n, err);
@@ -558,6 +888,12 @@ struct Launch {
     static void expect_infinity(hipStream_t s, const void *scratch, uint64_t n, int *err) {
         if (!n) return;
         hipLaunchKernelGGL(expect_infinity_kernel<G>, grid(n), dim3(256), 0, s, (const typename G::J *)scratch, n, err);
+    }
+    static void endo_subgroup(hipStream_t s, const uint8_t *in, int cin, uint64_t n, int *err) {
+        if constexpr (G::J::CfgT::ENDO_KIND != 0) {
+            if (!n) return;
+            hipLaunchKernelGGL(endo_subgroup_kernel<G>, grid(n), dim3(256), 0, s, in, cin, n, err);
+        }
     }
     static void decompress(hipStream_t s, const uint8_t *in, uint8_t *out, uint64_t n, int check_nonzero, int *err) {
         if (!n) return;
@@ -581,9 +917,17 @@ struct Launch {
         o.window_scalar_mul = window_scalar_mul;
         o.on_curve = on_curve;
         o.reduce_sum = reduce_sum;
+        o.affine_bytes = sizeof(typename G::A);
+        o.msm_prepare = msm_prepare;
+        o.msm_accumulate = msm_accumulate;
+        o.msm_combine = msm_combine;
+        o.msm_bucket_reduce = msm_bucket_reduce;
+        o.reduce_rows = reduce_rows;
+        o.msm_horner = msm_horner;
         o.fixed_scalar_mul = fixed_scalar_mul;
         o.normalize = normalize;
         o.expect_infinity = expect_infinity;
+        o.endo_subgroup = G::J::CfgT::ENDO_KIND != 0 ? endo_subgroup : nullptr;
         o.decompress = decompress;
         o.group_order = Fr::Params::MOD;
         o.decompress_host = decompress_host;

@@ -267,14 +267,15 @@ def _splitmix64(z):
 
 
 def power_pairs_coefficient(seed: bytes, idx: int, fr_bits: int) -> int:
-    """The coefficient rho_idx that ptau_power_pairs uses (documented PRF, kernels_impl.hpp::prf_word)."""
+    """The coefficient rho_idx that ptau_power_pairs uses (documented PRF, kernels_impl.hpp::prf_word):
+    PRF_BITS = 127 random bits — words 0..3 of the per-index stream, top bit cleared."""
     s0, s1 = int.from_bytes(seed[:8], "little"), int.from_bytes(seed[8:16], "little")
     nl = (fr_bits + 31) // 32
     v = 0
-    for j in range(nl):
+    for j in range(4):
         z = _splitmix64((s0 + (idx * nl + j + 1) * 0x9E3779B97F4A7C15) & MASK64) ^ s1
         v |= (_splitmix64(z) >> 32) << (32 * j)
-    return v & ((1 << (fr_bits - 1)) - 1)
+    return v & ((1 << 127) - 1)
 
 
 def power_pairs(curve, group, data: bytes, n, seed: bytes = None, index_base=0, compressed_in=False, device=0):

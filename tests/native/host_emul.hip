@@ -4,6 +4,9 @@
 //
 // usage: host_emul <op> <curve> <group> <n> <start> <cin> <cout> <tau_hex> <coeff_hex|-> < in > out
 //   op = apply | decompress
+//        subgroup : stdin = n points; stdout = n bytes of error bits (0 = in the prime-order subgroup)
+//        msm  : stdin = n points (uncompressed) then n x Fr::N u32 scalar limbs; <start> = window bits c (0 = the
+//               library's own plan), <cout> = 1 adds the shifted sum (needs n + 1 points); stdout = 1 or 2 points
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -32,7 +35,67 @@ static int run(const std::string &op, uint64_t n, uint64_t start, int cin, int c
     std::vector<uint8_t> in(n * isz), out;
     if (fread(in.data(), 1, in.size(), stdin) != in.size()) return 2;
     int bad = 0;
-    if (op == "decompress") {
+    if (op == "msm") {
+        // the per-thread bodies of the bucket MSM (K4), serial on the CPU, same order of launches as capi.hip
+        using J = typename G::J;
+        const int nsum = cout ? 2 : 1;
+        const uint64_t npts = n + (nsum - 1);
+        in.resize(npts * G::UNCOMP);
+        if (nsum == 2 && fread(in.data() + n * G::UNCOMP, 1, G::UNCOMP, stdin) != (size_t)G::UNCOMP) return 2;
+        std::vector<uint32_t> k32(n * G::Fr::N);
+        if (n && fread(k32.data(), 4, k32.size(), stdin) != k32.size()) return 2;
+        MsmPlan pl;
+        int lg = 0;
+        while ((2ull << lg) <= std::max<uint64_t>(n, 1)) lg++;
+        pl.c = start ? (int)start : std::max(2, std::min(16, lg - 4));
+        pl.W = (G::Fr::Params::BITS + 1 + pl.c - 1) / pl.c;
+        pl.B = 1u << (pl.c - 1);
+        pl.seg = std::min<uint32_t>(pl.B, 8);
+        const uint64_t wb = (uint64_t)pl.W * pl.B;
+        std::vector<typename G::A> aff(npts);
+        std::vector<uint32_t> dig(pl.W * std::max<uint64_t>(n, 1)), sorted(dig.size()), counts(wb, 0), offsets(wb + 1), run_offsets(wb + 1);
+        ScalarSource src{SCALAR_ARRAY, k32.data(), 0, 0, 0};
+        for (uint64_t i = 0; i < npts; i++) bad |= msm_prepare_thread<G>(in.data(), 0, aff.data(), dig.data(), counts.data(), npts, n, i, src, pl);
+        uint32_t run = 0, rrun = 0;
+        for (uint64_t j = 0; j < wb; j++) {
+            offsets[j] = run; run_offsets[j] = rrun;
+            run += counts[j]; rrun += (counts[j] + MSM_RUN - 1) / MSM_RUN;
+            counts[j] = offsets[j];
+        }
+        offsets[wb] = run; run_offsets[wb] = rrun;
+        for (uint64_t i = 0; i < n; i++) msm_scatter_thread(dig.data(), counts.data(), sorted.data(), n, i, pl);
+        std::vector<J> buckets(nsum * wb), parts(nsum * wb), runs(rrun + 1);
+        for (int sidx = 0; sidx < nsum; sidx++) {
+            for (uint32_t v = 0; v < rrun; v++)
+                msm_accumulate_thread<G>(aff.data(), sorted.data(), offsets.data(), run_offsets.data(), runs.data(), sidx, (uint32_t)wb, v);
+            for (uint64_t t = 0; t < wb; t++) msm_combine_thread<G>(runs.data(), run_offsets.data(), buckets.data() + sidx * wb, t);
+        }
+        const uint32_t rows = nsum * pl.W;
+        uint32_t cols = pl.B / pl.seg;
+        for (uint64_t t = 0; t < (uint64_t)rows * cols; t++) msm_bucket_reduce_thread<G>(buckets.data(), parts.data(), pl, t);
+        J *cur = parts.data(), *nxt = buckets.data();
+        while (cols > 1) {
+            const uint32_t T = (cols + 15) / 16;
+            for (uint64_t id = 0; id < (uint64_t)rows * T; id++) reduce_rows_thread<G>(cur, nxt, cols, T, id);
+            std::swap(cur, nxt);
+            cols = T;
+        }
+        std::vector<J> fin(nsum);
+        for (int sidx = 0; sidx < nsum; sidx++) msm_horner_thread<G>(cur + sidx * pl.W, &fin[sidx], pl);
+        std::vector<typename G::F> pre(nsum);
+        out.resize(nsum * G::UNCOMP);
+        for (int t = 0; t < nsum; t++) bad |= normalize_thread<G>(fin.data(), pre.data(), out.data(), 0, nsum, nsum, t, 0);
+    } else if (op == "subgroup") {
+        // endomorphism membership test (K3'), one result byte (error bits) per point
+        out.resize(n);
+        if constexpr (G::J::CfgT::ENDO_KIND != 0) {
+            for (uint64_t i = 0; i < n; i++) out[i] = (uint8_t)endo_subgroup_thread<G>(in.data(), cin, i);
+        } else {
+            return 4;
+        }
+        fwrite(out.data(), 1, out.size(), stdout);
+        return 0;
+    } else if (op == "decompress") {
         out.resize(n * G::UNCOMP);
         for (uint64_t i = 0; i < n; i++) bad |= decompress_thread<G>(in.data(), out.data(), i, 0);
     } else {

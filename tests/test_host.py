@@ -99,3 +99,84 @@ def test_kernel_bodies_on_host_match_golden(name, golden):
         d = subprocess.run([exe, "decompress", str(cid), str(grp), str(cnt), "0", "1", "0", "0", "-"],
                            input=response[ooff:ooff + cnt * csz], capture_output=True)
         assert d.returncode == 0 and len(d.stdout) == cnt * usz
+
+
+@pytest.mark.parametrize("name,group,n,c", [("bls12_377", 1, 300, 0), ("bls12_377", 1, 300, 2), ("bls12_377", 1, 37, 5), ("bls12_377", 2, 60, 4),
+                                            ("bw6", 1, 40, 3), ("mnt4_753", 2, 12, 6), ("mnt6_753", 1, 20, 0)])
+def test_bucket_msm_bodies_on_host(name, group, n, c, cref):
+    """The bucket-MSM kernels' per-thread bodies (digits, counting sort, bucket sums, running-sum reduction,
+    Horner), run serially on the CPU by host_emul, against the oracle's sum of scalar multiplications —
+    plain sum and the shifted sum of power_pairs, with repeated points, negations, infinities and edge scalars."""
+    import random
+    import struct
+    from oracle.pyref import serde
+    from oracle.pyref.ec import Group
+    exe = os.path.join(ROOT, "tests", "native", "host_emul")
+    if not os.path.exists(exe):
+        pytest.skip("host_emul not built")
+    cv = CURVES[name]
+    G = Group(cv, group)
+    rng = random.Random(1000 + n)
+    base = [G.mul(G.gen, rng.randrange(1, cv.r)) for _ in range(4)]
+    base.append(G.neg(base[0]))
+    pts = [base[i % 5] if i % 7 else None for i in range(n + 1)]
+    data = serde.write_batch(G, pts, False)
+    nl32 = (cv.r.bit_length() + 31) // 32
+    scalars = [rng.randrange(cv.r) for _ in range(n)]
+    scalars[0], scalars[1], scalars[2], scalars[3] = 0, 1, cv.r - 1, (1 << (cv.r.bit_length() - 1)) - 1
+    sbytes = b"".join(struct.pack("<%dI" % nl32, *[(s >> (32 * j)) & 0xFFFFFFFF for j in range(nl32)]) for s in scalars)
+    cid = CURVE_NAMES.index(name)
+    usz = G.uncomp_size
+    nl = cref.fr_limbs(name)
+    exp_a = cref.msm(name, group, data, n, scalars, nl)
+    exp_b = cref.msm(name, group, data[usz:], n, scalars, nl)
+    r = subprocess.run([exe, "msm", str(cid), str(group), str(n), str(c), "0", "0", "0", "-"], input=data[:n * usz] + sbytes,
+                       capture_output=True)
+    assert r.returncode == 0 and r.stdout == exp_a
+    r = subprocess.run([exe, "msm", str(cid), str(group), str(n), str(c), "0", "1", "0", "-"], input=data + sbytes,
+                       capture_output=True)
+    assert r.returncode == 0 and r.stdout == exp_a + exp_b
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_endomorphism_subgroup_test_on_host(group):
+    """BLS12-377 membership test through the endomorphism (phi on G1, psi on G2): the kernel body, run on the CPU,
+    accepts exactly the points the oracle's [r]P == O accepts — subgroup points, cofactor-only points, mixed points,
+    small-order components, the point at infinity — for compressed and uncompressed encodings."""
+    import random
+    from oracle.pyref import serde
+    from oracle.pyref.ec import Group
+    exe = os.path.join(ROOT, "tests", "native", "host_emul")
+    if not os.path.exists(exe):
+        pytest.skip("host_emul not built")
+    cv = CURVES["bls12_377"]
+    G = Group(cv, group)
+    F = G.F
+    rng = random.Random(group)
+
+    def rand_point():
+        while True:
+            x = tuple(rng.randrange(cv.q) for _ in range(F.deg))
+            y = F.sqrt(F.add(F.add(F.mul(F.sqr(x), x), F.mul(G.a, x)), G.b))
+            if y is not None:
+                return (x, y)
+    pts = [G.gen, G.mul(G.gen, rng.randrange(1, cv.r)), None]
+    for _ in range(3 if group == 1 else 2):
+        P = rand_point()
+        pts += [P, G.mul(P, cv.r), G.add(G.mul(P, cv.r), G.gen)]
+    if group == 1:   # components of small order (the G1 cofactor is 2^92 * 3 * ...): r * (h / f) * P
+        h = 0x170b5d44300000000000000000000000
+        P = rand_point()
+        pts += [G.mul(P, cv.r * (h // f)) for f in (2, 3, 4)]
+    expect = bytes(0 if G.in_subgroup(P) else 8 for P in pts)
+    assert 8 in expect and 0 in expect
+    for comp in (0, 1):
+        data = serde.write_batch(G, pts, bool(comp))
+        r = subprocess.run([exe, "subgroup", "0", str(group), str(len(pts)), "0", str(comp), "0", "0", "-"], input=data,
+                           capture_output=True)
+        assert r.returncode == 0 and r.stdout == expect
+    # uncompressed point off the curve
+    x, y = pts[0]
+    off = serde.write_point(G, (x, F.add(y, F.one())), False)
+    r = subprocess.run([exe, "subgroup", "0", str(group), "1", "0", "0", "0", "0", "-"], input=off, capture_output=True)
+    assert r.stdout == bytes([2])
