@@ -24,7 +24,9 @@ struct Fp2 {
     PTAU_HD static Fp2 sub(const Fp2 &a, const Fp2 &b) { return {F::sub(a.c0, b.c0), F::sub(a.c1, b.c1)}; }
     PTAU_HD static Fp2 neg(const Fp2 &a) { return {F::neg(a.c0), F::neg(a.c1)}; }
     PTAU_HD static Fp2 dbl(const Fp2 &a) { return {F::dbl(a.c0), F::dbl(a.c1)}; }
-    static constexpr bool MUL_OUT_OF_LINE = true;
+    // Over a 12-limb base the three base products are register-ABI calls (Fp::mul_vec), so the Karatsuba glue is
+    // inlined and operands never leave the VGPRs; over 24 limbs the whole product is one by-reference function.
+    static constexpr bool MUL_OUT_OF_LINE = (F::N > 12);
     __host__ __device__ __noinline__ static Fp2 mul_out(const Fp2 &a, const Fp2 &b) { return mul_inl(a, b); }
     __host__ __device__ __noinline__ static Fp2 sqr_out(const Fp2 &a) { return sqr_inl(a); }
     PTAU_HD static Fp2 mul(const Fp2 &a, const Fp2 &b) {

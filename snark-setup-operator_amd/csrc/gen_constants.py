@@ -120,6 +120,14 @@ def main():
             s.append("  static constexpr uint64_t ENDO_X = 0x%xull;" % endo[1])
             s.append("  static constexpr uint32_t ENDO_C0[%d] = {%s};" % (n, limbs(endo[2] * R % p, n)))
             s.append("  static constexpr uint32_t ENDO_C1[%d] = {%s};" % (n, limbs(endo[3] * R % p, n)))
+            if endo[0] == 2:
+                # psi^j (X, Y, Z) = (C0^j conj^j(X), C1^j conj^j(Y), conj^j(Z)), j = 1..3: rows (C0^j, C1^j) for the
+                # 4-dimensional decomposition k = k0 + k1 X + k2 X^2 + k3 X^3 (psi acts as [X] on G2, r < X^4)
+                rows = []
+                for j in (1, 2, 3):
+                    rows.append("{%s}" % limbs(pow(endo[2], j, p) * R % p, n))
+                    rows.append("{%s}" % limbs(pow(endo[3], j, p) * R % p, n))
+                s.append("  static constexpr uint32_t GLS_C[6][%d] = {%s};" % (n, ",\n    ".join(rows)))
         if glv:
             # phi(x, y) = (BETA x, y) = LAMBDA * (x, y) on the prime-order subgroup; k = k1 + k2*LAMBDA with
             # k2 = floor(k / LAMBDA), both below 2^127.  GLV_M = floor(2^256 / LAMBDA) for the reciprocal division.

@@ -13,6 +13,10 @@
 #pragma once
 #include "ec.hpp"
 
+#ifndef PTAU_MIN_WAVES_WIDE
+#define PTAU_MIN_WAVES_WIDE 0
+#endif
+
 namespace ptau {
 
 // Error bits accumulated in a device word by the kernels.
@@ -31,6 +35,10 @@ struct GroupTypes {
     using A = Affine<F>;
     static constexpr int COMP = F::BYTES;
     static constexpr int UNCOMP = 2 * F::BYTES;
+    // Waves per SIMD the kernels are compiled for (0 = the compiler's choice).  Point operations over the wide fields
+    // take all 512 unified registers (256 VGPRs + 256 AGPRs) and run ONE wave per SIMD; the bound only reaches the
+    // kernel body, not its out-of-line callees, so it is off by default (-DPTAU_MIN_WAVES_WIDE=2 for experiments).
+    static constexpr int MIN_WAVES = PTAU_MIN_WAVES_WIDE > 0 && sizeof(F) > 48 ? PTAU_MIN_WAVES_WIDE : 1;
 };
 
 // table layout: [0] = base coefficient c*tau^start, [1+k] = tau^(2^k); all Montgomery, Fr::N limbs
@@ -102,7 +110,7 @@ PTAU_HD int scalar_mul_thread(const uint8_t *in, int compressed_in, typename G::
 }
 
 template <class G>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, G::MIN_WAVES)
 scalar_mul_kernel(const uint8_t *__restrict__ in, int compressed_in, typename G::J *__restrict__ scratch,
                   uint64_t n, const uint32_t *__restrict__ table, int check_input, int *__restrict__ err) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -228,6 +236,41 @@ PTAU_HD void glv_decompose(const uint32_t (&k)[8], uint32_t (&k1)[4], uint32_t (
     for (int i = 0; i < 4; i++) { k1[i] = rem[i]; k2[i] = qh[i]; }
 }
 
+// 4-dimensional decomposition for BLS12 G2 (Galbraith-Scott): psi = twist^-1 o Frobenius o twist acts as [X] on the
+// prime-order subgroup and r = X^4 - X^2 + 1 < X^4, so the base-X digits of k, k = k0 + k1 X + k2 X^2 + k3 X^3 with
+// 0 <= k_j < X < 2^64, give k P = sum_j k_j psi^j(P): 64 doublings instead of 253.  Three restoring divisions by the
+// 64-bit constant X, bit-serial (a few thousand integer operations against ~3 M for the multiplication itself).
+// Valid ONLY for points of the prime-order subgroup, like the G1 GLV path.
+template <class Cfg>
+PTAU_HD void gls4_decompose(const uint32_t (&k)[8], uint64_t (&d)[4]) {
+    constexpr uint64_t X = Cfg::ENDO_X;
+    uint64_t q[4];
+#pragma unroll
+    for (int l = 0; l < 4; l++) q[l] = (uint64_t)k[2 * l] | ((uint64_t)k[2 * l + 1] << 32);
+    for (int j = 0; j < 3; j++) {
+        uint64_t rem = 0, nq[4];
+#pragma unroll
+        for (int l = 3; l >= 0; l--) {
+            uint64_t w = q[l], out = 0;
+            for (int b = 0; b < 64; b++) {
+                const uint64_t top = rem >> 63;
+                rem = (rem << 1) | (w >> 63);
+                w <<= 1;
+                out <<= 1;
+                if (top || rem >= X) {   // true value rem + 2^64 top is below 2X: one subtraction, wrap-around exact
+                    rem -= X;
+                    out |= 1;
+                }
+            }
+            nq[l] = out;
+        }
+        d[j] = rem;
+#pragma unroll
+        for (int l = 0; l < 4; l++) q[l] = nq[l];
+    }
+    d[3] = q[0];
+}
+
 constexpr int WINDOW_BITS = 4;
 constexpr int WINDOW_ENTRIES = 8;
 
@@ -298,6 +341,58 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
             return 0;
         }
     }
+    if constexpr (Cfg::ENDO_KIND == 2 && NL == 8) {
+        if (use_glv) {
+            // k P = sum_j k_j psi^j(P): four 64-bit sub-scalars, interleaved signed 4-bit windows over ONE table of
+            // multiples of P; psi^j is applied to the table entry on the fly (two Fq2-by-Fq products + conjugations).
+            using B = typename F::Base;
+            uint64_t dj[4];
+            gls4_decompose<Cfg>(k, dj);
+            uint64_t lo[4];
+            uint32_t hi[4];
+#pragma unroll
+            for (int h = 0; h < 4; h++) {   // + 0x8_8888_8888_8888_8888: 17 nibbles, every digit = nibble - 8
+                lo[h] = dj[h] + 0x8888888888888888ull;
+                hi[h] = 8u + (lo[h] < dj[h] ? 1u : 0u);
+            }
+            J acc = J::infinity();
+            for (int w = 16; w >= 0; w--) {
+                if (!acc.is_inf()) {
+#pragma nounroll
+                    for (int d = 0; d < WINDOW_BITS; d++) acc = J::dbl(acc);
+                }
+#pragma nounroll
+                for (int h = 0; h < 4; h++) {
+                    uint64_t l64 = 0;
+                    uint32_t h32 = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { l64 = (j == h) ? lo[j] : l64; h32 = (j == h) ? hi[j] : h32; }
+                    const uint32_t nib = w == 16 ? h32 : (uint32_t)(l64 >> (4 * w)) & 15u;
+                    const int dgt = (int)nib - 8;
+                    if (dgt != 0) {
+                        const int mag = dgt < 0 ? -dgt : dgt;
+                        J ent = wtab[(uint64_t)(mag - 1) * n + i];
+                        if (h) {
+                            B cx, cy;
+#pragma unroll
+                            for (int j = 0; j < B::N; j++) { cx.l[j] = Cfg::GLS_C[2 * (h - 1)][j]; cy.l[j] = Cfg::GLS_C[2 * (h - 1) + 1][j]; }
+                            if (h & 1) {   // odd powers of psi conjugate
+                                ent.X.c1 = B::neg(ent.X.c1);
+                                ent.Y.c1 = B::neg(ent.Y.c1);
+                                ent.Z.c1 = B::neg(ent.Z.c1);
+                            }
+                            ent.X = F::mul_base(ent.X, cx);
+                            ent.Y = F::mul_base(ent.Y, cy);
+                        }
+                        if (dgt < 0) ent.Y = F::neg(ent.Y);
+                        acc = J::add(acc, ent);
+                    }
+                }
+            }
+            scratch[i] = acc;
+            return 0;
+        }
+    }
     uint32_t c = 0;
 #pragma unroll
     for (int j = 0; j < NL; j++) k[j] = addc(k[j], 0x88888888u, c);
@@ -322,14 +417,17 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
     return 0;
 }
 
-template <class G>
-__global__ void __launch_bounds__(256)
-window_scalar_mul_kernel(const uint8_t *__restrict__ in, int compressed_in, typename G::J *__restrict__ scratch,
+// CIN is a template parameter: the square root behind a compressed read is a register-hungry callee and a kernel's
+// VGPR allocation is the maximum over its call graph — the uncompressed instance (the tau-update of a challenge)
+// does not carry it.
+template <class G, int CIN>
+__global__ void __launch_bounds__(256, G::MIN_WAVES)
+window_scalar_mul_kernel(const uint8_t *__restrict__ in, typename G::J *__restrict__ scratch,
                          typename G::J *__restrict__ wtab, uint64_t n, ScalarSource src, int check_input,
                          int use_glv, int *__restrict__ err) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    int bad = window_scalar_mul_thread<G>(in, compressed_in, scratch, wtab, n, i, src, check_input, use_glv);
+    int bad = window_scalar_mul_thread<G>(in, CIN, scratch, wtab, n, i, src, check_input, use_glv);
     if (bad) atomicOr(err, bad);
 }
 
@@ -342,7 +440,7 @@ PTAU_HD void reduce_sum_thread(const typename G::J *in, typename G::J *out, uint
     out[t] = acc;
 }
 template <class G>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, G::MIN_WAVES)
 reduce_sum_kernel(const typename G::J *__restrict__ in, typename G::J *__restrict__ out, uint64_t n, uint64_t T) {
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
@@ -420,7 +518,7 @@ PTAU_HD int msm_prepare_thread(const uint8_t *in, int compressed_in, typename G:
     return bad;
 }
 template <class G>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, G::MIN_WAVES)
 msm_prepare_kernel(const uint8_t *__restrict__ in, int compressed_in, typename G::A *__restrict__ aff,
                    uint32_t *__restrict__ dig, uint32_t *__restrict__ counts, uint64_t n_points, uint64_t n_scalars,
                    ScalarSource src, MsmPlan pl, int *__restrict__ err) {
@@ -481,7 +579,7 @@ PTAU_HD void msm_accumulate_thread(const typename G::A *aff, const uint32_t *sor
     partials[v] = acc;
 }
 template <class G>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, G::MIN_WAVES)
 msm_accumulate_kernel(const typename G::A *__restrict__ aff, const uint32_t *__restrict__ sorted,
                       const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ run_offsets,
                       typename G::J *__restrict__ partials, uint32_t shift, uint32_t total_buckets) {
@@ -499,7 +597,7 @@ PTAU_HD void msm_combine_thread(const typename G::J *partials, const uint32_t *r
     buckets[t] = acc;
 }
 template <class G>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, G::MIN_WAVES)
 msm_combine_kernel(const typename G::J *__restrict__ partials, const uint32_t *__restrict__ run_offsets,
                    typename G::J *__restrict__ buckets, uint64_t total_buckets) {
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -530,7 +628,7 @@ PTAU_HD void msm_bucket_reduce_thread(const typename G::J *buckets, typename G::
     parts[t] = tot;
 }
 template <class G>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, G::MIN_WAVES)
 msm_bucket_reduce_kernel(const typename G::J *__restrict__ buckets, typename G::J *__restrict__ parts, MsmPlan pl,
                          uint64_t total) {
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -548,7 +646,7 @@ PTAU_HD void reduce_rows_thread(const typename G::J *in, typename G::J *out, uin
     out[id] = acc;
 }
 template <class G>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, G::MIN_WAVES)
 reduce_rows_kernel(const typename G::J *__restrict__ in, typename G::J *__restrict__ out, uint32_t cols, uint32_t T,
                    uint64_t total) {
     uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -584,7 +682,7 @@ PTAU_HD int on_curve_thread(const uint8_t *in, uint64_t i) {
     return F::sqr(p.y) == curve_rhs<F, typename G::J::CfgT>(p.x) ? 0 : ERRBIT_NOT_ON_CURVE;
 }
 template <class G>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, G::MIN_WAVES)
 on_curve_kernel(const uint8_t *__restrict__ in, uint64_t n, int *__restrict__ err) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -638,7 +736,7 @@ PTAU_HD int endo_subgroup_thread(const uint8_t *in, int compressed_in, uint64_t 
     return ok ? 0 : ERRBIT_NOT_IN_SUBGROUP;
 }
 template <class G>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, G::MIN_WAVES)
 endo_subgroup_kernel(const uint8_t *__restrict__ in, int compressed_in, uint64_t n, int *__restrict__ err) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -669,7 +767,7 @@ PTAU_HD int fixed_scalar_mul_thread(const uint8_t *in, int compressed_in, typena
 }
 
 template <class G>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, G::MIN_WAVES)
 fixed_scalar_mul_kernel(const uint8_t *__restrict__ in, int compressed_in, typename G::J *__restrict__ scratch,
                         uint64_t n, const uint32_t *__restrict__ scalar, int nbits, int *__restrict__ err) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -717,7 +815,7 @@ PTAU_HD int normalize_thread(const typename G::J *scratch, typename G::F *pre, u
 }
 
 template <class G>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, G::MIN_WAVES)
 normalize_kernel(const typename G::J *__restrict__ scratch, typename G::F *__restrict__ pre,
                  uint8_t *__restrict__ out, int compressed_out, uint64_t n, uint64_t T,
                  int check_nonzero, int *__restrict__ err) {
@@ -729,7 +827,7 @@ normalize_kernel(const typename G::J *__restrict__ scratch, typename G::F *__res
 
 // Flag every scratch point that is NOT the point at infinity (subgroup check: r*P must be O).
 template <class G>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, G::MIN_WAVES)
 expect_infinity_kernel(const typename G::J *__restrict__ scratch, uint64_t n, int *__restrict__ err) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -753,7 +851,7 @@ PTAU_HD int decompress_thread(const uint8_t *in, uint8_t *out, uint64_t i, int c
 }
 
 template <class G>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, G::MIN_WAVES)
 decompress_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, uint64_t n, int check_nonzero,
                   int *__restrict__ err) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -835,8 +933,12 @@ struct Launch {
     static void window_scalar_mul(hipStream_t s, const uint8_t *in, int cin, void *scratch, void *wtab, uint64_t n,
                                   ScalarSource src, int check_input, int use_glv, int *err) {
         if (!n) return;
-        hipLaunchKernelGGL(window_scalar_mul_kernel<G>, grid(n), dim3(256), 0, s, in, cin, (typename G::J *)scratch,
-                           (typename G::J *)wtab, n, src, check_input, use_glv, err);
+        if (cin)
+            hipLaunchKernelGGL((window_scalar_mul_kernel<G, 1>), grid(n), dim3(256), 0, s, in, (typename G::J *)scratch,
+                               (typename G::J *)wtab, n, src, check_input, use_glv, err);
+        else
+            hipLaunchKernelGGL((window_scalar_mul_kernel<G, 0>), grid(n), dim3(256), 0, s, in, (typename G::J *)scratch,
+                               (typename G::J *)wtab, n, src, check_input, use_glv, err);
     }
     static void reduce_sum(hipStream_t s, const void *in, void *out, uint64_t n, uint64_t T) {
         if (!T) return;

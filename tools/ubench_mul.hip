@@ -19,6 +19,7 @@ __global__ void __launch_bounds__(256) k(F *io, int iters) {
         if (MODE == 1) { a = F::mul_inl(a, b); b = F::mul_inl(b, a); }
         if (MODE == 2) { a = F::sqr(a); b = F::sqr(b); }
         if (MODE == 3) { a = F::sqr_inl(a); b = F::sqr_inl(b); }
+        if (MODE == 4) { F t = F::mul_inl(a, b); F u = F::mul_inl(b, b); a = t; b = u; }   // two INDEPENDENT products per iteration (ILP 2)
     }
     io[256 + t] = F::add(a, b);
 }
@@ -44,12 +45,14 @@ int main() {
     for (int i = 0; i < 256; i++) { uint32_t c[12]; for (int j = 0; j < 12; j++) c[j] = (i * 2654435761u + j * 40503u) ^ (j << 20); c[11] &= 0x00ffffff; h[i] = F::from_canonical(c); }
     F *d; hipMalloc(&d, sizeof(F) * (256 + 4096 * 256));
     hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice);
-    F o0[256], o1[256], o2[256], o3[256];
-    for (int blocks : {1024, 2048, 3072}) {
+    F o0[256], o1[256], o2[256], o3[256], o4[256];
+    // 256 blocks = one wave per SIMD (no other wave hides the MAC dependency chain); 512 = two; >= 1024 = four and more
+    for (int blocks : {256, 512, 1024, 2048, 3072}) {
         run<0>("FIPS call", d, blocks, o0);
         run<1>("FIPS inline", d, blocks, o1);
         run<2>("SQR call", d, blocks, o2);
         run<3>("SQR inline", d, blocks, o3);
+        run<4>("FIPS inline x2 ILP", d, blocks, o4);
     }
     // host reference: the same templates compiled for the CPU
     int bad = 0;
