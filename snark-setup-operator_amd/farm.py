@@ -7,6 +7,7 @@ own GPU and only the 64-byte response hashes are exchanged at the end (all_gathe
 gloo in the CPU tests).  Second-half chunks (start >= 2^power) carry only tauG1 (about 1/5 of the work
 of a full chunk), so assignment is longest-processing-time-first rather than round-robin.
 """
+import os
 from typing import Callable, Dict, List, Sequence, Tuple
 
 
@@ -46,3 +47,85 @@ def run_farm(n_chunks: int, weights: Sequence[float], process_chunk: Callable[[i
             result[i] = h
     assert sorted(result) == list(range(n_chunks)), "a chunk was dropped or duplicated by the farm"
     return result
+
+
+# ---- final transcript ratio check, sharded (SURVEY §8(e) collective C1) ---------------------------------------
+# Phase1::aggregate_verification (phase1_cli::transform_ratios; /root/reference/src/bin/control.rs:587-591,
+# src/bin/verify_transcript.rs:646-653, 812-822) reduces each full-length vector to ONE pair
+# (sum rho_i v_i, sum rho_i v_{i+1}) and tests it with two pairings.  The reduction is linear, so each rank reduces
+# a contiguous slice of pair indices with the SAME coefficient stream (the generator is keyed by a shared 16-byte
+# seed and the GLOBAL index, ptau_power_pairs' index_base); the per-rank partial pairs are exchanged with ONE
+# all_gather per vector (2 points x world_size, RCCL over xGMI on GPUs / gloo in the CPU tests), summed, and the
+# O(1) pairing tail runs once.  Slices overlap by one element: pair (i, i+1) straddles the boundary.
+
+def slice_bounds(n_pairs: int, world: int, rank: int) -> Tuple[int, int]:
+    """Pair-index range [lo, hi) of `rank`: contiguous, balanced to within one pair, empty when n_pairs < world."""
+    base, extra = divmod(n_pairs, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def accumulator_vectors(point_sizes: Dict[int, int], powers_g1_length: int, powers_length: int):
+    """(name, group, byte offset, element count) of the four power vectors in a Full-mode uncompressed accumulator,
+    plus the offset of betaG2.  point_sizes = {1: g1 uncompressed bytes, 2: g2 uncompressed bytes}."""
+    u1, u2 = point_sizes[1], point_sizes[2]
+    o = 64
+    out = []
+    for name, grp, cnt in (("tau_g1", 1, powers_g1_length), ("tau_g2", 2, powers_length), ("alpha_g1", 1, powers_length),
+                           ("beta_g1", 1, powers_length)):
+        out.append((name, grp, o, cnt))
+        o += cnt * point_sizes[grp]
+    return out, o
+
+
+def sharded_transform_ratios(combined: bytes, point_sizes: Dict[int, int], powers_g1_length: int, powers_length: int,
+                             power_pairs: Callable, sum_points: Callable, check_same_ratio: Callable, dist=None,
+                             seed: bytes = None) -> bool:
+    """transform_ratios with the four vector reductions split over the ranks of `dist`.
+
+    power_pairs(group, data, n, seed, index_base) -> (a, b)   reduces n consecutive points (n - 1 pairs) of one slice;
+    sum_points(group, [points])                 -> point     adds serialized points;
+    check_same_ratio((a, b), (c, d))            -> bool      the pairing test, G1 pair vs G2 pair.
+    On GPUs these are phase1_cli.power_pairs / dense_multiexp with unit scalars / check_same_ratio; the CPU tests
+    inject oracle stand-ins.  Every rank returns the same verdict."""
+    import torch
+    world = dist.get_world_size() if dist is not None else 1
+    rank = dist.get_rank() if dist is not None else 0
+    dev = "cuda" if (dist is not None and dist.get_backend() == "nccl") else "cpu"
+    if seed is None:
+        seed = os.urandom(16)
+    if dist is not None:   # one coefficient stream for the whole vector: rank 0's seed
+        t = torch.frombuffer(bytearray(seed), dtype=torch.uint8).to(dev)
+        dist.broadcast(t, src=0)
+        seed = bytes(t.cpu().numpy().tobytes())
+    vectors, beta_g2_off = accumulator_vectors(point_sizes, powers_g1_length, powers_length)
+    reduced = {}
+    for name, grp, off, cnt in vectors:
+        usz = point_sizes[grp]
+        lo, hi = slice_bounds(cnt - 1, world, rank)
+        if hi > lo:      # points lo .. hi inclusive
+            a, b = power_pairs(grp, combined[off + lo * usz: off + (hi + 1) * usz], hi - lo + 1, seed, lo)
+            part = a + b + b"\x01"
+        else:
+            part = bytes(2 * usz) + b"\x00"      # no pairs on this rank
+        if dist is not None:
+            mine = torch.frombuffer(bytearray(part), dtype=torch.uint8).to(dev)
+            gathered = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(gathered, mine)
+            parts = [bytes(g.cpu().numpy().tobytes()) for g in gathered]
+        else:
+            parts = [part]
+        parts = [p for p in parts if p[-1]]
+        reduced[name] = (sum_points(grp, [p[:usz] for p in parts]), sum_points(grp, [p[usz:2 * usz] for p in parts]))
+    u1, u2 = point_sizes[1], point_sizes[2]
+    v = {name: off for name, _, off, _ in vectors}
+    tau_g1_01 = (combined[v["tau_g1"]: v["tau_g1"] + u1], combined[v["tau_g1"] + u1: v["tau_g1"] + 2 * u1])
+    tau_g2_01 = (combined[v["tau_g2"]: v["tau_g2"] + u2], combined[v["tau_g2"] + u2: v["tau_g2"] + 2 * u2])
+    ok = True
+    for name in ("tau_g1", "alpha_g1", "beta_g1"):
+        ok = ok and check_same_ratio(reduced[name], tau_g2_01)
+    ok = ok and check_same_ratio(tau_g1_01, reduced["tau_g2"])
+    beta_g1_0 = combined[v["beta_g1"]: v["beta_g1"] + u1]
+    beta_g2 = combined[beta_g2_off: beta_g2_off + u2]
+    ok = ok and check_same_ratio((tau_g1_01[0], beta_g1_0), (tau_g2_01[0], beta_g2))
+    return bool(ok)

@@ -338,6 +338,31 @@ def transform_ratios(combined: bytes, check_input_correctness, full_parameters: 
                                        int(check_input_correctness), device, eb, len(eb)), eb)
 
 
+def transform_ratios_sharded(combined: bytes, full_parameters: Phase1Parameters, dist=None, device=0, seed: bytes = None) -> None:
+    """phase1_cli::transform_ratios with the vector reductions split over the ranks of an initialised
+    torch.distributed group (one process per GPU; farm.sharded_transform_ratios): each rank runs ptau_power_pairs on
+    its slice with the shared coefficient stream, ONE all_gather of the partial pairs per vector (RCCL over xGMI),
+    the partial sums go through ptau_msm with unit scalars, the pairing tail runs on the host.
+    Raises PtauError(-6) on every rank when a ratio check fails."""
+    from . import farm
+    curve = full_parameters.curve
+    L = _lib.load_library()
+    sizes = {1: L.ptau_point_size(curve, 1, 0), 2: L.ptau_point_size(curve, 2, 0)}
+
+    def pp(grp, data, n, sd, index_base):
+        return power_pairs(curve, grp, data, n, seed=sd, index_base=index_base, device=device)
+
+    def sum_points(grp, pts):
+        return dense_multiexp(curve, grp, b"".join(pts), [1] * len(pts), device=device)
+
+    def check(g1p, g2p):
+        return check_same_ratio(curve, g1p, g2p)
+    ok = farm.sharded_transform_ratios(combined, sizes, full_parameters.powers_g1_length, full_parameters.powers_length,
+                                       pp, sum_points, check, dist=dist, seed=seed)
+    if not ok:
+        raise _lib.PtauError(-6, "power ratio check failed (sharded transform_ratios)")
+
+
 def verify_pok(challenge: bytes, response: bytes, g2_s: bytes, parameters: Phase1Parameters):
     """Proof-of-knowledge + chunk-0 before/after checks of Phase1::verification; g2_s from the host's compute_g2_s."""
     L = _lib.load_library()
