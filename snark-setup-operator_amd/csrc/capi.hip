@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <future>
 #include <mutex>
 #include <string>
@@ -263,16 +264,7 @@ bool use_bucket_msm() {
 
 constexpr uint64_t MSM_SLICE_POINTS = 1ull << 22;   // points per bucket pass (u32 sort indices, bounded workspace)
 
-ptau::MsmPlan msm_plan(uint64_t m, int scalar_bits) {
-    int lg = 0;
-    while ((2ull << lg) <= m) lg++;
-    ptau::MsmPlan pl;
-    pl.c = std::max(2, std::min(16, lg - 4));    // ~32 points per bucket; >= 2^18 bucket threads at 2^20 points
-    pl.W = (scalar_bits + 1 + pl.c - 1) / pl.c;
-    pl.B = 1u << (pl.c - 1);
-    pl.seg = std::min<uint32_t>(pl.B, 8);
-    return pl;
-}
+using ptau::msm_plan;
 
 // sum_i k_i * P_i (i < n) -> ONE serialized affine point in host memory; with out_b also the SHIFTED sum
 // sum_i k_i * P_{i+1} (power_pairs: d_in must then hold n + 1 points).  Bucket method (K4); caller holds the
@@ -892,10 +884,20 @@ int ptau_subgroup_check(int curve, int group, const uint8_t *in, int compressed_
     return run_subgroup_check_dev(c, curve, group, ops, (const uint8_t *)c->d_in, compressed_in, n, err);
 }
 
-int ptau_verify_chunk(const ptau_params *p, const uint8_t *challenge, size_t challenge_len, const uint8_t *response,
+}  // extern "C"
+
+namespace {
+// The three digests of a chunk verification (the `.hash` side files of transform_pok_and_correctness).  Each file is
+// hashed exactly ONCE, on its own host thread, while the GPU works: BLAKE2b(challenge) and BLAKE2b(response) start
+// at once; BLAKE2b(new_challenge) trails the device, consuming each vector as soon as its D2H copy has landed.
+struct VerifyDigests {
+    uint8_t challenge[64], response[64], new_challenge[64];
+};
+
+int verify_chunk_impl(const ptau_params *p, const uint8_t *challenge, size_t challenge_len, const uint8_t *response,
                       size_t response_len, uint8_t *new_challenge, size_t new_challenge_len, int check_input,
                       int check_output, int subgroup_check_mode, int ratio_check, const uint8_t *tau_g2_check,
-                      int device, char *errbuf, size_t err_len) {
+                      int device, VerifyDigests *digests, char *errbuf, size_t err_len) {
     Err err{errbuf, err_len};
     int rc = check_params(p, err);
     if (rc) return rc;
@@ -913,17 +915,46 @@ int ptau_verify_chunk(const ptau_params *p, const uint8_t *challenge, size_t cha
     auto fut_chain = std::async(std::launch::async, [=] {
         uint8_t d[64];
         ptau_blake2b512(challenge, challenge_len, d);
+        if (digests) memcpy(digests->challenge, d, 64);
         return memcmp(d, response, 64) == 0;
     });
-    auto fut_resp = std::async(std::launch::async, [=] { ptau_blake2b512(response, response_len, new_challenge); });
+    std::shared_future<void> fut_resp = std::async(std::launch::async, [=] {
+        ptau_blake2b512(response, response_len, new_challenge);
+        if (digests) memcpy(digests->response, new_challenge, 64);
+    }).share();
+    std::atomic<size_t> nc_ready{64};     // bytes of new_challenge final so far (the header counts once fut_resp is done)
+    std::atomic<bool> nc_abort{false};
+    std::future<void> fut_nc;
+    if (digests)
+        fut_nc = std::async(std::launch::async, [&, fut_resp] {
+            fut_resp.wait();
+            Blake2b b;
+            size_t done = 0;
+            while (done < new_challenge_len) {
+                if (nc_abort.load(std::memory_order_acquire)) return;
+                const size_t r = nc_ready.load(std::memory_order_acquire);
+                if (r > done) {
+                    b.update(new_challenge + done, r - done);
+                    done = r;
+                } else {
+                    usleep(200);
+                }
+            }
+            b.finish(digests->new_challenge);
+        });
     struct Joiner {   // never leave a worker running past the caller's buffers
         std::future<bool> &a;
-        std::future<void> &b;
+        std::shared_future<void> &b;
+        std::future<void> &c;
+        std::atomic<bool> &abort_flag;
+        bool ok = false;
         ~Joiner() {
+            if (!ok) abort_flag.store(true, std::memory_order_release);
             if (a.valid()) a.wait();
             if (b.valid()) b.wait();
+            if (c.valid()) c.wait();
         }
-    } joiner{fut_chain, fut_resp};
+    } joiner{fut_chain, fut_resp, fut_nc, nc_abort};
     const GroupOps *g1 = get_ops(p->curve, 1), *g2 = get_ops(p->curve, 2);
     DeviceCtx *c;
     if ((rc = ensure_ctx(device, c, err))) return rc;
@@ -956,6 +987,7 @@ int ptau_verify_chunk(const ptau_params *p, const uint8_t *challenge, size_t cha
             return rc;
         pi += v.n * v.ops->comp;
         po += v.n * v.ops->uncomp;
+        nc_ready.store((size_t)(po - new_challenge), std::memory_order_release);
     }
     if (ratio_check) {
         // check_power_ratios: consecutive elements of every vector differ by the SAME factor tau, i.e.
@@ -991,10 +1023,23 @@ int ptau_verify_chunk(const ptau_params *p, const uint8_t *challenge, size_t cha
         if (bad_rc) return err.fail(bad_rc, "malformed ratio pair for %s", bad_name);
     }
     // new_challenge = BLAKE2b(response) | decompressed elements
-    fut_resp.get();
+    fut_resp.wait();
     if (!fut_chain.get())
         return err.fail(PTAU_E_HASH_CHAIN, "response does not start with the hash of the challenge it claims to extend");
+    joiner.ok = true;
+    if (fut_nc.valid()) fut_nc.wait();
     return PTAU_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int ptau_verify_chunk(const ptau_params *p, const uint8_t *challenge, size_t challenge_len, const uint8_t *response,
+                      size_t response_len, uint8_t *new_challenge, size_t new_challenge_len, int check_input,
+                      int check_output, int subgroup_check_mode, int ratio_check, const uint8_t *tau_g2_check,
+                      int device, char *errbuf, size_t err_len) {
+    return verify_chunk_impl(p, challenge, challenge_len, response, response_len, new_challenge, new_challenge_len, check_input,
+                             check_output, subgroup_check_mode, ratio_check, tau_g2_check, device, nullptr, errbuf, err_len);
 }
 
 int ptau_transform_pok_and_correctness_file(const ptau_params *p, const char *challenge_path, const char *challenge_hash_path,
@@ -1016,19 +1061,20 @@ int ptau_transform_pok_and_correctness_file(const ptau_params *p, const char *ch
     if (ch.len != sz.accumulator_size || resp.len != sz.contribution_size)
         return err.fail(PTAU_E_LEN, "challenge/response file sizes %zu/%zu do not match the parameters (%llu/%llu)", ch.len,
                         resp.len, (unsigned long long)sz.accumulator_size, (unsigned long long)sz.contribution_size);
-    uint8_t digest[64];
-    ptau_blake2b512((const uint8_t *)ch.p, ch.len, digest);
-    if ((rc = write_small_file(challenge_hash_path, digest, 64, err))) return rc;
-    ptau_blake2b512((const uint8_t *)resp.p, resp.len, digest);
-    if ((rc = write_small_file(response_hash_path, digest, 64, err))) return rc;
     if ((rc = nc.create_new(new_challenge_path, sz.accumulator_size, err))) return rc;
-    if ((rc = ptau_verify_chunk(p, (const uint8_t *)ch.p, ch.len, (const uint8_t *)resp.p, resp.len, (uint8_t *)nc.p, nc.len,
-                                check_input, check_output, subgroup_check_mode, ratio_check, tau_g2_check, device, errbuf,
-                                err_len)))
-        return rc;
-    ptau_blake2b512((const uint8_t *)nc.p, nc.len, digest);
+    VerifyDigests dg;
+    rc = verify_chunk_impl(p, (const uint8_t *)ch.p, ch.len, (const uint8_t *)resp.p, resp.len, (uint8_t *)nc.p, nc.len, check_input,
+                           check_output, subgroup_check_mode, ratio_check, tau_g2_check, device, &dg, errbuf, err_len);
+    // the reference writes challenge.hash and response.hash before it verifies: keep them on the failure paths that got that far
+    if (rc == PTAU_OK || rc == PTAU_E_HASH_CHAIN || rc == PTAU_E_INVALID_RATIO || rc == PTAU_E_NOT_IN_SUBGROUP ||
+        rc == PTAU_E_POINT_AT_INFINITY || rc == PTAU_E_POINT) {
+        int rc2;
+        if ((rc2 = write_small_file(challenge_hash_path, dg.challenge, 64, err))) return rc2;
+        if ((rc2 = write_small_file(response_hash_path, dg.response, 64, err))) return rc2;
+    }
+    if (rc) return rc;
     if (msync(nc.p, nc.len, MS_SYNC)) return err.fail(PTAU_E_IO, "msync failed: %s", strerror(errno));
-    return write_small_file(new_challenge_hash_path, digest, 64, err);
+    return write_small_file(new_challenge_hash_path, dg.new_challenge, 64, err);
 }
 
 int ptau_msm(int curve, int group, const uint8_t *in, int compressed_in, uint64_t n, const uint64_t *scalars, uint8_t *out,

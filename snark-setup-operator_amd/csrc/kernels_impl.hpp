@@ -467,6 +467,33 @@ struct MsmPlan {
     uint32_t seg;     // buckets per bucket-reduce thread
 };
 
+// Window width for m points and `scalar_bits`-bit scalars (host side).  Cost model: W windows, each m mixed additions
+// plus ~3 addition-equivalents per bucket for the running-sum reduction; a plan whose TOP window holds fewer than
+// c - 2 scalar bits is rejected when another one exists (its few buckets would each collect m / 2^t points: the run
+// splitting keeps that parallel, but the combine pass then walks long run lists).  127-bit power_pairs coefficients
+// at 2^20 points give c = 16: 8 full windows, 32 points per bucket.
+inline MsmPlan msm_plan(uint64_t m, int scalar_bits, int force_c = 0) {
+    MsmPlan best{};
+    double best_cost = -1;
+    bool best_balanced = false;
+    for (int c = 2; c <= 16; c++) {
+        if (force_c && c != force_c) continue;
+        const int W = (scalar_bits + 1 + c - 1) / c;
+        const int top_bits = scalar_bits + 1 - (W - 1) * c;
+        const bool balanced = top_bits >= c - 2;
+        const double cost = (double)W * ((double)m + 3.0 * (double)(1u << (c - 1)));
+        if (best_cost < 0 || (balanced && !best_balanced) || (balanced == best_balanced && cost < best_cost)) {
+            best.c = c;
+            best.W = W;
+            best.B = 1u << (c - 1);
+            best.seg = best.B < 8 ? best.B : 8;
+            best_cost = cost;
+            best_balanced = balanced;
+        }
+    }
+    return best;
+}
+
 PTAU_HD uint32_t atomic_inc_u32(uint32_t *p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return atomicAdd(p, 1u);

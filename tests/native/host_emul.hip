@@ -44,13 +44,7 @@ static int run(const std::string &op, uint64_t n, uint64_t start, int cin, int c
         if (nsum == 2 && fread(in.data() + n * G::UNCOMP, 1, G::UNCOMP, stdin) != (size_t)G::UNCOMP) return 2;
         std::vector<uint32_t> k32(n * G::Fr::N);
         if (n && fread(k32.data(), 4, k32.size(), stdin) != k32.size()) return 2;
-        MsmPlan pl;
-        int lg = 0;
-        while ((2ull << lg) <= std::max<uint64_t>(n, 1)) lg++;
-        pl.c = start ? (int)start : std::max(2, std::min(16, lg - 4));
-        pl.W = (G::Fr::Params::BITS + 1 + pl.c - 1) / pl.c;
-        pl.B = 1u << (pl.c - 1);
-        pl.seg = std::min<uint32_t>(pl.B, 8);
+        const MsmPlan pl = msm_plan(std::max<uint64_t>(n, 1), G::Fr::Params::BITS, (int)start);
         const uint64_t wb = (uint64_t)pl.W * pl.B;
         std::vector<typename G::A> aff(npts);
         std::vector<uint32_t> dig(pl.W * std::max<uint64_t>(n, 1)), sorted(dig.size()), counts(wb, 0), offsets(wb + 1), run_offsets(wb + 1);
