@@ -21,13 +21,13 @@ struct CurveConsts {
     }
     PTAU_HD static F coeff_a() {
         if constexpr (F::DEG == 1) return base_from(Cfg::A0);
-        else if constexpr (F::DEG == 2) return F{base_from(Cfg::A0), base_from(Cfg::A1)};
-        else return F{base_from(Cfg::A0), base_from(Cfg::A1), base_from(Cfg::A2)};
+        else if constexpr (F::DEG == 2) return F::make(base_from(Cfg::A0), base_from(Cfg::A1));
+        else return F::make(base_from(Cfg::A0), base_from(Cfg::A1), base_from(Cfg::A2));
     }
     PTAU_HD static F coeff_b() {
         if constexpr (F::DEG == 1) return base_from(Cfg::B0);
-        else if constexpr (F::DEG == 2) return F{base_from(Cfg::B0), base_from(Cfg::B1)};
-        else return F{base_from(Cfg::B0), base_from(Cfg::B1), base_from(Cfg::B2)};
+        else if constexpr (F::DEG == 2) return F::make(base_from(Cfg::B0), base_from(Cfg::B1));
+        else return F::make(base_from(Cfg::B0), base_from(Cfg::B1), base_from(Cfg::B2));
     }
 };
 

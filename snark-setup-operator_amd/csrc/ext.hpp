@@ -57,6 +57,9 @@ struct Fp2 {
         return r;
     }
     PTAU_HD static Fp2 mul_base(const Fp2 &a, const F &k) { return {F::mul(a.c0, k), F::mul(a.c1, k)}; }
+    PTAU_HD static Fp2 make(const F &c0, const F &c1) { return {c0, c1}; }
+    PTAU_HD static Fp2 conj(const Fp2 &a) { return {a.c0, F::neg(a.c1)}; }
+    static constexpr int LANES = 1;   // lanes of a wavefront that hold one element
     __host__ __device__ __noinline__ static Fp2 inverse(const Fp2 &a) {
         F n = F::sub(F::sqr(a.c0), F::mul_small(F::sqr(a.c1), NR));
         F ni = F::inverse(n);
@@ -105,6 +108,115 @@ struct Fp2 {
     }
 };
 
+// ---- Fq2 spread over a LANE PAIR --------------------------------------------------------------------------
+// One element a0 + a1 u lives in two adjacent lanes: the even lane holds a0, the odd lane a1 (N VGPRs each instead of
+// 2N in one lane).  A Jacobian G2 point then costs what a G1 point costs in registers (36 VGPRs per lane), point
+// operations stay inlined at <= 256 VGPRs without spills and the kernel runs 2+ waves per SIMD — a single-lane Fq2
+// point operation takes all 512 unified registers, spills, and runs at one third of the multiplier peak.
+// Products need the partner's coefficient: one DPP quad_perm [1,0,3,2] move per limb.  Schoolbook instead of
+// Karatsuba (4 base products on 2 lanes = 2 per lane), complex squaring (1 per lane).  Every lane of a pair executes
+// the same instruction stream; all data-dependent branches in the callers are pair-uniform by construction
+// (is_zero / == combine both lanes).  Device only: the CPU emulation of the kernel bodies uses Fp2.
+PTAU_HD uint32_t lane_parity() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return threadIdx.x & 1u;
+#else
+    return 0;
+#endif
+}
+PTAU_HD uint32_t lane_xchg(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+#else
+    return v;
+#endif
+}
+
+template <class F, int NR>
+struct Fp2L {
+    static constexpr int DEG = 2;
+    static constexpr int BYTES = 2 * F::BYTES;
+    static constexpr int LANES = 2;
+    static constexpr bool MUL_OUT_OF_LINE = false;
+    using Base = F;
+    F c;   // a0 on even lanes, a1 on odd lanes
+
+    PTAU_HD static F other(const F &v) {
+        F r;
+#pragma unroll
+        for (int i = 0; i < F::N; i++) r.l[i] = lane_xchg(v.l[i]);
+        return r;
+    }
+    PTAU_HD static F sel(bool odd, const F &if_odd, const F &if_even) {
+        F r;
+#pragma unroll
+        for (int i = 0; i < F::N; i++) r.l[i] = odd ? if_odd.l[i] : if_even.l[i];
+        return r;
+    }
+    PTAU_HD static bool both(bool mine) { return mine && (lane_xchg(mine ? 1u : 0u) != 0u); }
+
+    PTAU_HD static Fp2L make(const F &c0, const F &c1) { return {lane_parity() ? c1 : c0}; }
+    PTAU_HD static Fp2L zero() { return {F::zero()}; }
+    PTAU_HD static Fp2L one() { return {lane_parity() ? F::zero() : F::one()}; }
+    PTAU_HD bool is_zero() const { return both(c.is_zero()); }
+    PTAU_HD bool operator==(const Fp2L &b) const { return both(c == b.c); }
+    PTAU_HD bool operator!=(const Fp2L &b) const { return !(*this == b); }
+    PTAU_HD static Fp2L add(const Fp2L &a, const Fp2L &b) { return {F::add(a.c, b.c)}; }
+    PTAU_HD static Fp2L sub(const Fp2L &a, const Fp2L &b) { return {F::sub(a.c, b.c)}; }
+    PTAU_HD static Fp2L neg(const Fp2L &a) { return {F::neg(a.c)}; }
+    PTAU_HD static Fp2L dbl(const Fp2L &a) { return {F::dbl(a.c)}; }
+    PTAU_HD static Fp2L conj(const Fp2L &a) { return {lane_parity() ? F::neg(a.c) : a.c}; }
+    PTAU_HD static Fp2L mul_base(const Fp2L &a, const F &k) { return {F::mul(a.c, k)}; }
+    // even: a0 b0 + NR a1 b1      odd: a1 b0 + a0 b1
+    PTAU_HD static Fp2L mul(const Fp2L &a, const Fp2L &b) {
+        const bool odd = lane_parity() != 0;
+        const F ao = other(a.c), bo = other(b.c);
+        const F t1 = F::mul(a.c, sel(odd, bo, b.c));    // even: a0 b0   odd: a1 b0
+        const F t2 = F::mul(ao, sel(odd, b.c, bo));     // even: a1 b1   odd: a0 b1
+        return {F::add(t1, sel(odd, t2, F::mul_small(t2, NR)))};
+    }
+    // complex squaring, one base product per lane:  even: (a0 + a1)(a0 + NR a1)   odd: a0 a1
+    PTAU_HD static Fp2L sqr(const Fp2L &a) {
+        const bool odd = lane_parity() != 0;
+        const F ao = other(a.c);
+        const F l = sel(odd, ao, F::add(a.c, ao));
+        const F r = sel(odd, a.c, F::add(a.c, F::mul_small(ao, NR)));
+        const F t = F::mul(l, r);
+        const F v = other(t);                            // even lanes receive v = a0 a1
+        const F even = F::sub(F::sub(t, v), F::mul_small(v, NR));
+        return {sel(odd, F::dbl(t), even)};
+    }
+    __device__ __noinline__ static Fp2L inverse(const Fp2L &a) {
+        const bool odd = lane_parity() != 0;
+        const F sq = F::sqr(a.c), sqo = other(sq);
+        const F n = F::sub(sel(odd, sqo, sq), F::mul_small(sel(odd, sq, sqo), NR));   // a0^2 - NR a1^2 on both lanes
+        const F ni = F::inverse(n);
+        const F r = F::mul(a.c, ni);
+        return {sel(odd, F::neg(r), r)};
+    }
+    // compressed input never reaches the lane-pair instances (capi.hip dispatches them for uncompressed points only)
+    PTAU_HD static bool sqrt(const Fp2L &, Fp2L &out) { out = zero(); return false; }
+    PTAU_HD static bool read_bytes(const uint8_t *in, bool with_flags, uint8_t *flags, Fp2L &out) {
+        const bool odd = lane_parity() != 0;
+        uint8_t fl = 0;
+        bool ok = F::read_bytes(in + (odd ? F::BYTES : 0), with_flags && odd, &fl, out.c);
+        if (with_flags) *flags = (uint8_t)(odd ? fl : lane_xchg(fl));   // the flag bits sit in the last byte of a1
+        return both(ok);
+    }
+    PTAU_HD void write_bytes(uint8_t *out, uint8_t flags) const {
+        const bool odd = lane_parity() != 0;
+        c.write_bytes(out + (odd ? F::BYTES : 0), odd ? flags : (uint8_t)0);
+    }
+    // arkworks Ord: highest coefficient first
+    PTAU_HD int sign_class() const {
+        const bool odd = lane_parity() != 0;
+        const int mine = c.sign_class();
+        const int theirs = (int)lane_xchg((uint32_t)mine);
+        const int s1 = odd ? mine : theirs, s0 = odd ? theirs : mine;
+        return s1 ? s1 : s0;
+    }
+};
+
 template <class F, int NR>
 struct Fp3 {
     static constexpr int DEG = 3;
@@ -140,6 +252,8 @@ struct Fp3 {
         return r;
     }
     PTAU_HD static Fp3 sqr(const Fp3 &a) { return mul(a, a); }
+    PTAU_HD static Fp3 make(const F &c0, const F &c1, const F &c2) { return {c0, c1, c2}; }
+    static constexpr int LANES = 1;
     __host__ __device__ __noinline__ static Fp3 inverse(const Fp3 &a) {
         F t0 = F::sub(F::sqr(a.c0), F::mul_small(F::mul(a.c1, a.c2), NR));
         F t1 = F::sub(F::mul_small(F::sqr(a.c2), NR), F::mul(a.c0, a.c1));

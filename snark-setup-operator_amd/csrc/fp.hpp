@@ -75,6 +75,7 @@ template <class P>
 struct Fp {
     static constexpr int N = P::N;
     static constexpr int DEG = 1;
+    static constexpr int LANES = 1;          // lanes of a wavefront that hold one element
     static constexpr int BYTES = P::BYTES;   // serialized size of one element
     using Base = Fp<P>;
     using Params = P;

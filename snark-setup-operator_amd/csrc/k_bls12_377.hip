@@ -4,10 +4,11 @@
 namespace ptau {
 using G1T = GroupTypes<BlsFq, BlsFr, BlsG1Cfg>;
 using G2T = GroupTypes<BlsFq, BlsFr, BlsG2Cfg>;
+using G2L = GroupTypes<BlsFq, BlsFr, BlsG2Cfg, true>;   // Fq2 over lane pairs (tau-update of uncompressed points)
 
 const GroupOps *ops_bls12_377(int group) {
     static const GroupOps o1 = Launch<G1T>::ops();
-    static const GroupOps o2 = Launch<G2T>::ops();
+    static const GroupOps o2 = Launch<G2T, G2L>::ops();
     return group == 1 ? &o1 : (group == 2 ? &o2 : nullptr);
 }
 }  // namespace ptau

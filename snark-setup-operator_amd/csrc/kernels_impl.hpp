@@ -11,8 +11,14 @@
 //   normalize_kernel  : Montgomery-trick batched inversion (one inversion per K points), affine
 //                       conversion, arkworks serialisation (sign flag from the canonical y).
 #pragma once
+#include <cstdlib>
+#include <type_traits>
+
 #include "ec.hpp"
 
+#ifndef PTAU_LANE_MIN_WAVES
+#define PTAU_LANE_MIN_WAVES 2
+#endif
 #ifndef PTAU_MIN_WAVES_WIDE
 #define PTAU_MIN_WAVES_WIDE 0
 #endif
@@ -25,20 +31,24 @@ enum : int { ERRBIT_NONCANONICAL = 1, ERRBIT_NOT_ON_CURVE = 2, ERRBIT_INFINITY =
 constexpr int SCALAR_TABLE_ENTRIES = 64;   // tau^(2^k), k < 64, preceded by the base coefficient
 
 // Host+device view of one group's types.
-template <class FqP, class FrP, class Cfg>
+template <class FqP, class FrP, class Cfg, bool LANE_PAIR = false>
 struct GroupTypes {
     using Fq = Fp<FqP>;
     using Fr = Fp<FrP>;
+    // LANE_PAIR: an Fq2 element spread over two adjacent lanes (Fp2L, ext.hpp) — two threads per point
     using F = std::conditional_t<Cfg::DEG == 1, Fq,
-              std::conditional_t<Cfg::DEG == 2, Fp2<Fq, Cfg::NR>, Fp3<Fq, Cfg::NR>>>;
+              std::conditional_t<Cfg::DEG == 2, std::conditional_t<LANE_PAIR, Fp2L<Fq, Cfg::NR>, Fp2<Fq, Cfg::NR>>,
+                                 Fp3<Fq, Cfg::NR>>>;
+    static constexpr int LPP = F::LANES;   // lanes (threads) per point
     using J = Jac<F, Cfg>;
     using A = Affine<F>;
     static constexpr int COMP = F::BYTES;
     static constexpr int UNCOMP = 2 * F::BYTES;
-    // Waves per SIMD the kernels are compiled for (0 = the compiler's choice).  Point operations over the wide fields
+    // Waves per SIMD the kernels are compiled for (0 = the compiler's choice; lane-pair groups inline everything and
+    // are held to 256 registers = two waves).  Point operations over the wide fields
     // take all 512 unified registers (256 VGPRs + 256 AGPRs) and run ONE wave per SIMD; the bound only reaches the
     // kernel body, not its out-of-line callees, so it is off by default (-DPTAU_MIN_WAVES_WIDE=2 for experiments).
-    static constexpr int MIN_WAVES = PTAU_MIN_WAVES_WIDE > 0 && sizeof(F) > 48 ? PTAU_MIN_WAVES_WIDE : 1;
+    static constexpr int MIN_WAVES = LPP == 2 ? PTAU_LANE_MIN_WAVES : (PTAU_MIN_WAVES_WIDE > 0 && sizeof(F) > 48 ? PTAU_MIN_WAVES_WIDE : 1);
 };
 
 // table layout: [0] = base coefficient c*tau^start, [1+k] = tau^(2^k); all Montgomery, Fr::N limbs
@@ -274,6 +284,20 @@ PTAU_HD void gls4_decompose(const uint32_t (&k)[8], uint64_t (&d)[4]) {
 constexpr int WINDOW_BITS = 4;
 constexpr int WINDOW_ENTRIES = 8;
 
+// Result store in the STANDARD Jacobian layout (X.c0 X.c1 Y.c0 Y.c1 Z.c0 Z.c1 for Fq2) whatever the lane mapping,
+// so normalize_kernel of the single-lane group type reads what a lane-pair kernel wrote.
+template <class G>
+PTAU_HD void store_jac(typename G::J *scratch, uint64_t i, const typename G::J &v) {
+    if constexpr (G::LPP == 2) {
+        typename G::Fq *base = reinterpret_cast<typename G::Fq *>(scratch) + i * 6 + lane_parity();
+        base[0] = v.X.c;
+        base[2] = v.Y.c;
+        base[4] = v.Z.c;
+    } else {
+        scratch[i] = v;
+    }
+}
+
 template <class G>
 PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typename G::J *scratch,
                                      typename G::J *wtab, uint64_t n, uint64_t i, const ScalarSource &src,
@@ -289,15 +313,16 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
     int bad = read_point_any<G>(in, compressed_in, i, p);
     if ((check_input & 1) && p.inf) bad |= ERRBIT_INFINITY;
     if (bad || p.inf) {
-        scratch[i] = J::infinity();
+        store_jac<G>(scratch, i, J::infinity());
         return bad;
     }
-    // table: e -> (e+1) * P
+    // table: e -> (e+1) * P   (lane-pair groups: one half-width Jacobian per lane, the pair adjacent)
+    const uint64_t slot = i * G::LPP + (G::LPP == 2 ? lane_parity() : 0u), nslots = n * G::LPP;
     J cur = J::from_affine(p);
-    wtab[i] = cur;
+    wtab[slot] = cur;
     for (int e = 1; e < WINDOW_ENTRIES; e++) {
         cur = J::add_mixed(cur, p);
-        wtab[(uint64_t)e * n + i] = cur;
+        wtab[(uint64_t)e * nslots + slot] = cur;
     }
     uint32_t k[NL];
     thread_scalar<Fr>(src, i, k);
@@ -330,14 +355,14 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
                     int dgt = (int)((limb >> ((w & 7) * 4)) & 15u) - 8;
                     if (dgt != 0) {
                         int mag = dgt < 0 ? -dgt : dgt;
-                        J ent = wtab[(uint64_t)(mag - 1) * n + i];
+                        J ent = wtab[(uint64_t)(mag - 1) * nslots + slot];
                         if (h) ent.X = F::mul(ent.X, beta);
                         if (dgt < 0) ent.Y = F::neg(ent.Y);
                         acc = J::add(acc, ent);
                     }
                 }
             }
-            scratch[i] = acc;
+            store_jac<G>(scratch, i, acc);
             return 0;
         }
     }
@@ -371,15 +396,15 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
                     const int dgt = (int)nib - 8;
                     if (dgt != 0) {
                         const int mag = dgt < 0 ? -dgt : dgt;
-                        J ent = wtab[(uint64_t)(mag - 1) * n + i];
+                        J ent = wtab[(uint64_t)(mag - 1) * nslots + slot];
                         if (h) {
                             B cx, cy;
 #pragma unroll
                             for (int j = 0; j < B::N; j++) { cx.l[j] = Cfg::GLS_C[2 * (h - 1)][j]; cy.l[j] = Cfg::GLS_C[2 * (h - 1) + 1][j]; }
                             if (h & 1) {   // odd powers of psi conjugate
-                                ent.X.c1 = B::neg(ent.X.c1);
-                                ent.Y.c1 = B::neg(ent.Y.c1);
-                                ent.Z.c1 = B::neg(ent.Z.c1);
+                                ent.X = F::conj(ent.X);
+                                ent.Y = F::conj(ent.Y);
+                                ent.Z = F::conj(ent.Z);
                             }
                             ent.X = F::mul_base(ent.X, cx);
                             ent.Y = F::mul_base(ent.Y, cy);
@@ -389,7 +414,7 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
                     }
                 }
             }
-            scratch[i] = acc;
+            store_jac<G>(scratch, i, acc);
             return 0;
         }
     }
@@ -408,12 +433,12 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
         int dgt = (int)((limb >> ((w & 7) * 4)) & 15u) - 8;
         if (dgt != 0) {
             int mag = dgt < 0 ? -dgt : dgt;
-            J ent = wtab[(uint64_t)(mag - 1) * n + i];
+            J ent = wtab[(uint64_t)(mag - 1) * nslots + slot];
             if (dgt < 0) ent.Y = F::neg(ent.Y);
             acc = J::add(acc, ent);
         }
     }
-    scratch[i] = acc;
+    store_jac<G>(scratch, i, acc);
     return 0;
 }
 
@@ -425,7 +450,7 @@ __global__ void __launch_bounds__(256, G::MIN_WAVES)
 window_scalar_mul_kernel(const uint8_t *__restrict__ in, typename G::J *__restrict__ scratch,
                          typename G::J *__restrict__ wtab, uint64_t n, ScalarSource src, int check_input,
                          int use_glv, int *__restrict__ err) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G::LPP;
     if (i >= n) return;
     int bad = window_scalar_mul_thread<G>(in, CIN, scratch, wtab, n, i, src, check_input, use_glv);
     if (bad) atomicOr(err, bad);
@@ -754,8 +779,8 @@ PTAU_HD int endo_subgroup_thread(const uint8_t *in, int compressed_in, uint64_t 
         ex = F::mul(p.x, c0);
         ey = F::neg(p.y);
     } else {
-        ex = F{B::mul(p.x.c0, c0), B::mul(B::neg(p.x.c1), c0)};
-        ey = F{B::mul(p.y.c0, c1), B::mul(B::neg(p.y.c1), c1)};
+        ex = F::mul_base(F::conj(p.x), c0);
+        ey = F::mul_base(F::conj(p.y), c1);
     }
     if (t.is_inf()) return ERRBIT_NOT_IN_SUBGROUP;
     const F zz = F::sqr(t.Z);
@@ -924,7 +949,17 @@ struct GroupOps {
     int (*decompress_host)(const uint8_t *in, uint8_t *out, uint64_t n, int check_nonzero);
 };
 
-template <class G>
+// PTAU_LANE_PAIR=0 keeps Fq2 groups on the single-lane kernels (A/B runs).
+inline bool lane_pair_enabled() {
+    static const bool v = [] {
+        const char *e = getenv("PTAU_LANE_PAIR");
+        return !(e && e[0] == '0');
+    }();
+    return v;
+}
+
+// GL: the lane-pair twin of G (same curve, Fq2 elements over two lanes) or void.
+template <class G, class GL = void>
 struct Launch {
     using Fr = typename G::Fr;
     static dim3 grid(uint64_t n) { return dim3((unsigned)((n + 255) / 256)); }
@@ -960,6 +995,13 @@ struct Launch {
     static void window_scalar_mul(hipStream_t s, const uint8_t *in, int cin, void *scratch, void *wtab, uint64_t n,
                                   ScalarSource src, int check_input, int use_glv, int *err) {
         if (!n) return;
+        if constexpr (!std::is_void_v<GL>) {
+            if (!cin && lane_pair_enabled()) {   // two threads per point; results land in G's Jacobian layout
+                hipLaunchKernelGGL((window_scalar_mul_kernel<GL, 0>), grid(n * 2), dim3(256), 0, s, in, (typename GL::J *)scratch,
+                                   (typename GL::J *)wtab, n, src, check_input, use_glv, err);
+                return;
+            }
+        }
         if (cin)
             hipLaunchKernelGGL((window_scalar_mul_kernel<G, 1>), grid(n), dim3(256), 0, s, in, (typename G::J *)scratch,
                                (typename G::J *)wtab, n, src, check_input, use_glv, err);
