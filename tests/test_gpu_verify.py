@@ -273,3 +273,59 @@ def test_round_combine_and_transform_ratios(name, pkg):
     with pytest.raises(pkg.PtauError) as e:
         pkg.transform_ratios(mixed, pkg.CheckForCorrectness.No, full)
     assert e.value.code == -6
+
+
+def test_e2e_phase1_config1_files(pkg, cref, tmp_path):
+    """BASELINE configs[0] — e2e/e2ephase1.sh BLS12-377 --powers 12 --chunk-size 10 — through the FILE-level entry points
+    the operator calls: new_challenge, two rounds of contribute -> transform_pok_and_correctness on all 8 chunks
+    (4 full + 4 tauG1-only), then combine + transform_ratios on the last responses.  Hash chain and `.hash` side files
+    checked at every step; every response is bit-exact vs the C oracle's Phase1::computation."""
+    name, power, cs = "bls12_377", 12, 1 << 10
+    rng = random.Random(2024)
+    full = pkg.Phase1Parameters.new_full(name, 0, power, cs)
+    n_chunks = -(-full.powers_g1_length // cs)
+    assert n_chunks == 8
+    keys = [[rng.randrange(1, CURVES[name].r) for _ in range(3)] for _ in range(2)]
+    final_responses = []
+    tau_g2_check = [None, None]
+    for i in range(n_chunks):
+        prm = pkg.Phase1Parameters.new_chunk(name, 0, i, cs, 0, power, cs)
+        f = lambda s: str(tmp_path / ("chunk%d_%s" % (i, s)))
+        pkg.new_challenge(f("challenge0"), f("challenge0.hash"), prm)
+        ch = open(f("challenge0"), "rb").read()
+        assert len(ch) == prm.accumulator_size and ch[:64].hex().startswith("786a02f742015903c6c6fd852552d272")
+        assert open(f("challenge0.hash"), "rb").read() == pkg.calculate_hash(ch)
+        for rnd in range(2):
+            key = pkg.PrivateKey(*keys[rnd], bytes(range(256)) * 5 + bytes(prm.public_key_size - 1280))
+            c, r, nc = f("challenge%d" % rnd), f("response%d" % rnd), f("challenge%d" % (rnd + 1))
+            pkg.contribute(c, c + ".h", r, r + ".hash", pkg.CheckForCorrectness.No, pkg.BatchExpMode.Auto, prm, key)
+            chal, resp = open(c, "rb").read(), open(r, "rb").read()
+            assert resp[:64] == pkg.calculate_hash(chal) == open(c + ".h", "rb").read()
+            assert open(r + ".hash", "rb").read() == pkg.calculate_hash(resp)
+            assert resp[-prm.public_key_size:] == key.public_key
+            ref = cref.computation(name, 0, i, cs, power, chal, key.tau, key.alpha, key.beta, nthreads=8)
+            end = prm.contribution_size - prm.public_key_size
+            assert resp[64:end] == ref[64:end]
+            with pytest.raises(pkg.PtauError) as e:      # create_new semantics: the stale response is never overwritten
+                pkg.contribute(c, c + ".h", r, r + ".hash", pkg.CheckForCorrectness.No, pkg.BatchExpMode.Auto, prm, key)
+            assert e.value.code == -9
+            kw = {}
+            if prm.other_chunk_size == 0:
+                kw["tau_g2_check"] = tau_g2_check[rnd]
+            pkg.transform_pok_and_correctness(c, c + ".vh", pkg.CheckForCorrectness.No, r, r + ".vh",
+                                              pkg.CheckForCorrectness.OnlyNonZero, nc, nc + ".hash", pkg.SubgroupCheckMode.Auto,
+                                              True, prm, **kw)
+            new_ch = open(nc, "rb").read()
+            assert new_ch[:64] == pkg.calculate_hash(resp) == open(r + ".vh", "rb").read()
+            assert open(nc + ".hash", "rb").read() == pkg.calculate_hash(new_ch)
+            if i == 0:    # (tauG2[0], tauG2[1]) of this contribution, for the tauG1-only chunks
+                off = 64 + prm.g1_chunk_size * 96
+                tau_g2_check[rnd] = new_ch[off:off + 2 * 192]
+        final_responses.append(open(f("response1"), "rb").read())
+    combined = pkg.combine(final_responses, cs, full)
+    assert len(combined) == full.accumulator_size
+    pkg.transform_ratios(combined, pkg.CheckForCorrectness.Full, full)
+    # the combined accumulator is [ (tau0*tau1)^i G ]: element 1 of tauG1 is (tau0*tau1) G
+    t = keys[0][0] * keys[1][0] % CURVES[name].r
+    G1 = Group(CURVES[name], 1)
+    assert combined[64 + 96:64 + 192] == serde.write_point(G1, G1.mul(G1.gen, t), False)

@@ -8,7 +8,7 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 R=$PWD
-BENCH="python3 $R/bench.py --steps 3 --warmup 1 --no-extras"
+BENCH="python3 $R/bench.py --steps 3 --warmup 1 --no-extras --cpu-sample 4096"
 if [ "${SKIP_TESTS:-0}" != "1" ]; then
   timeout -k 10 900 python3 -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1 || { tail -30 $OUT/pytest_gpu.log; exit 1; }
   tail -3 $OUT/pytest_gpu.log
@@ -22,7 +22,7 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_W
   timeout -k 10 300 rocprofv3 --pmc $c -d $R/$OUT/pmc/$d -o pmc --output-format csv -- $BENCH > $R/$OUT/pmc_$d.log 2>&1 || { tail -5 $R/$OUT/pmc_$d.log; exit 1; }
 done
 cd $R
-python3 tools/pmc_summarize.py $OUT/pmc $OUT/pmc_summary.json "python3 bench.py --steps 3 --warmup 1 --no-extras"
+python3 tools/pmc_summarize.py $OUT/pmc $OUT/pmc_summary.json "python3 bench.py --steps 3 --warmup 1 --no-extras --cpu-sample 4096"
 find $OUT/stats -name '*kernel_stats.csv' -exec cp {} $OUT/kernel_stats.csv \;
 # keep the merged-back payload small
 find $OUT -name '*.db' -delete; find $OUT -name '*kernel_trace.csv' -delete; find $OUT -name '*counter_collection.csv' -size +20M -delete
