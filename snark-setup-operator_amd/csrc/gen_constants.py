@@ -23,6 +23,60 @@ MNT4_G2_GEN = ((1924102106809591678010150581920417786613031697849881317565545371
 MNT6_G2_GEN = ((29198358678412327442734962858329560226529221072203506456026012448974205216981182326430452963416355393639268348853246220872774645199447843650057899436615551635917170214459877469820960613629590429199233247184212848085187308734929, 5999018000412277550478365752247211689696853783805982998351836252998281861610577852123252644775525980463600111418780194099963317946867954670821792886908172141813419565404494811506209266206591269999903100596739427595314458089519, 23036363772691094229836333217253237353920846158487310676871760642047832279183406136277001090285869741581273000600403111152094511074649824913321839863262906656729226549952126760622546375112636258358119156419276720729160639100672), (12522487755151452321636296110912153312587696989961702566133508697902026427396806962507244285498832447641578601706432705688833318733498102202120773626092164224621750103182935392734181664799052801736670403192038344073075905997843, 16235015760916115964926011096856921961118902124478830012533377841076941038656095966540337882684172623620414493625906317184520934808353542572158474378847050339489727226648236649815074973737903207021589886131177308741763891478875, 23675364518124042074447951143077219100080642308580948340331650285500567862191598861219028945929831519063354710694882580486644431500405814964247718872347363192237308655443507138052713813465575167843055486399098470156176028246725))
 
 
+BW6_G1_XY = (0x01075b020ea190c8b277ce98a477beaee6a0cfb7551b27f0ee05c54b85f56fc779017ffac15520ac11dbfcd294c2e746a17a54ce47729b905bd71fa0c9ea097103758f9a280ca27f6750dd0356133e82055928aca6af603f4088f3af66e5b43d,
+             0x0058b84e0a6fc574e6fd637b45cc2a420f952589884c9ec61a7348d2a2e573a3265909f1af7e0dbac5b8fa1771b5b806cc685d31717a4c55be3fb90b6fc2cdd49f9df141b3053253b2b08119cad0fb93ad1cb2be0b20d2a1bafc8f2db4e95363)
+BW6_G2_XY = (0x0110133241d9b816c852a82e69d660f9d61053aac5a7115f4c06201013890f6d26b41c5dab3da268734ec3f1f09feb58c5bbcae9ac70e7c7963317a300e1b6bace6948cb3cd208d700e96efbc2ad54b06410cf4fe1bf995ba830c194cd025f1c,
+             0x0017c3357761369f8179eb10e4b6d2dc26b7cf9acec2181c81a78e2753ffe3160a1d86c80b95a59c94c97eb733293fef64f293dbd2c712b88906c170ffa823003ea96fcd504affc758aa2d3a3c5a02a591ec0594f9eac689eb70a16728c73b61)
+
+
+def ec_mul_j0(P, k, p):
+    """k*P on y^2 = x^3 + b over F_p (affine double-and-add; a = 0 so b is not needed)."""
+    def add(A, B):
+        if A is None:
+            return B
+        if B is None:
+            return A
+        (x1, y1), (x2, y2) = A, B
+        if x1 == x2:
+            if (y1 + y2) % p == 0:
+                return None
+            l = 3 * x1 * x1 * pow(2 * y1, -1, p) % p
+        else:
+            l = (y2 - y1) * pow(x2 - x1, -1, p) % p
+        x3 = (l * l - x1 - x2) % p
+        return (x3, (l * (x1 - x3) - y1) % p)
+    R = None
+    for bit in bin(k)[2:]:
+        R = add(R, R)
+        if bit == "1":
+            R = add(R, P)
+    return R
+
+
+def glv_beta_for(P, w, lam, p):
+    """The cube root of unity beta in {w, w^2} with (beta x, y) = lam * (x, y)."""
+    target = ec_mul_j0(P, lam, p)
+    for beta in (w, w * w % p):
+        if (beta * P[0] % p, P[1]) == target:
+            return beta
+    raise AssertionError("no cube root of unity matches lambda")
+
+
+def glv_lattice(r, lam):
+    """Two short vectors (a, b) with a + b*lam = 0 mod r (extended Euclid, GLV 2001)."""
+    rs, ts = [r, lam], [0, 1]
+    while rs[-1] * rs[-1] >= r:
+        qq = rs[-2] // rs[-1]
+        rs.append(rs[-2] - qq * rs[-1])
+        ts.append(ts[-2] - qq * ts[-1])
+    l = len(rs) - 1
+    v1 = (rs[l], -ts[l])
+    qq = rs[l - 1] // rs[l]
+    c1, c2 = (rs[l - 1], -ts[l - 1]), (rs[l - 1] - qq * rs[l], -(ts[l - 1] - qq * ts[l]))
+    v2 = c1 if c1[0] ** 2 + c1[1] ** 2 < c2[0] ** 2 + c2[1] ** 2 else c2
+    return v1, v2
+
+
 def limbs(x, n):
     return ", ".join("0x%08xu" % ((x >> (32 * i)) & 0xFFFFFFFF) for i in range(n))
 
@@ -108,7 +162,7 @@ def main():
     out.append("using Mnt4Fr = Mnt6Fq;")
     out.append("using Mnt6Fr = Mnt4Fq;")
 
-    def coeffs(cname, fname, deg, a, b, nr, glv=None, endo=None):
+    def coeffs(cname, fname, deg, a, b, nr, glv=None, endo=None, glv2=None):
         p, n, R = fields[fname]
         s = ["struct %s {" % cname]
         s.append("  static constexpr bool HAS_GLV = %s;" % ("true" if glv else "false"))
@@ -128,6 +182,38 @@ def main():
                     rows.append("{%s}" % limbs(pow(endo[2], j, p) * R % p, n))
                     rows.append("{%s}" % limbs(pow(endo[3], j, p) * R % p, n))
                 s.append("  static constexpr uint32_t GLS_C[6][%d] = {%s};" % (n, ",\n    ".join(rows)))
+        s.append("  static constexpr int GLV_KIND = %d;   // 0 none, 1 half-size lambda (floor division), 2 lattice (Babai rounding)" % (1 if glv else (2 if glv2 else 0)))
+        if glv2:
+            # phi(x, y) = (BETA x, y) = LAMBDA (x, y); short basis (a1, b1), (a2, b2) of {(u, v): u + v LAMBDA = 0 mod r};
+            # c_i = (k G_i) >> 384 approximates the Babai coefficients, k1 = k + E11 c1|a1| + E12 c2|a2|,
+            # k2 = E21 c1|b1| + E22 c2|b2|  (signed), |k1|, |k2| < 2^191 (checked over edge and random scalars below).
+            beta, lam, rr = glv2
+            (a1, b1), (a2, b2) = glv_lattice(rr, lam)
+            det = a1 * b2 - a2 * b1
+            assert abs(det) == rr
+            sg = lambda v: 1 if v >= 0 else -1
+            s1, s2 = sg(b2) * sg(det), -sg(b1) * sg(det)
+            g1, g2 = ((abs(b2) << 384) + rr // 2) // rr, ((abs(b1) << 384) + rr // 2) // rr
+            e11, e12, e21, e22 = -s1 * sg(a1), -s2 * sg(a2), -s1 * sg(b1), -s2 * sg(b2)
+            def decomp(k):
+                c1, c2 = (k * g1) >> 384, (k * g2) >> 384
+                return k + e11 * c1 * abs(a1) + e12 * c2 * abs(a2), e21 * c1 * abs(b1) + e22 * c2 * abs(b2)
+            import random as _r
+            rg = _r.Random(7)
+            for k in [0, 1, 2, rr - 1, rr - 2, rr // 2, rr // 3, lam, lam - 1, lam + 1] + [rg.randrange(rr) for _ in range(2000)]:
+                k1, k2 = decomp(k)
+                assert (k1 + k2 * lam - k) % rr == 0 and abs(k1) < 1 << 191 and abs(k2) < 1 << 191
+            for v in (a1, a2, b1, b2):
+                assert abs(v) < 1 << 192
+            assert g1 < 1 << 224 and g2 < 1 << 224
+            s.append("  static constexpr uint32_t GLV_BETA[%d] = {%s};" % (n, limbs(beta * R % p, n)))
+            s.append("  static constexpr uint32_t GLV2_A1[6] = {%s};" % limbs(abs(a1), 6))
+            s.append("  static constexpr uint32_t GLV2_A2[6] = {%s};" % limbs(abs(a2), 6))
+            s.append("  static constexpr uint32_t GLV2_B1[6] = {%s};" % limbs(abs(b1), 6))
+            s.append("  static constexpr uint32_t GLV2_B2[6] = {%s};" % limbs(abs(b2), 6))
+            s.append("  static constexpr uint32_t GLV2_G1[7] = {%s};" % limbs(g1, 7))
+            s.append("  static constexpr uint32_t GLV2_G2[7] = {%s};" % limbs(g2, 7))
+            s.append("  static constexpr int GLV2_E11 = %d, GLV2_E12 = %d, GLV2_E21 = %d, GLV2_E22 = %d;" % (e11, e12, e21, e22))
         if glv:
             # phi(x, y) = (BETA x, y) = LAMBDA * (x, y) on the prime-order subgroup; k = k1 + k2*LAMBDA with
             # k2 = floor(k / LAMBDA), both below 2^127.  GLV_M = floor(2^256 / LAMBDA) for the reciprocal division.
@@ -169,8 +255,20 @@ def main():
     psi_cx, psi_cy = fq2_pow_u((BLS_Q - 1) // 3), fq2_pow_u((BLS_Q - 1) // 2)
     assert psi_cx[1] == 0 and psi_cy[1] == 0
     out.append(coeffs("BlsG2Cfg", "BlsFq", 2, (0, 0), (0, BLS_G2_B1), -5, endo=(2, bls_x, psi_cx[0], psi_cy[0])))
-    out.append(coeffs("Bw6G1Cfg", "Bw6Fq", 1, (0,), (BW6_Q - 1,), 0))
-    out.append(coeffs("Bw6G2Cfg", "Bw6Fq", 1, (0,), (4,), 0))
+    # BW6-761: both groups are j = 0 curves over Fq; one eigenvalue lambda (316 bits), the matching cube root of unity
+    # per group (checked against the generators: phi(G) = lambda G)
+    gq = 2
+    while pow(gq, (BW6_Q - 1) // 3, BW6_Q) == 1:
+        gq += 1
+    bw6_w = pow(gq, (BW6_Q - 1) // 3, BW6_Q)
+    hr = 2
+    while pow(hr, (BLS_Q - 1) // 3, BLS_Q) == 1:
+        hr += 1
+    bw6_lam = pow(hr, 2 * (BLS_Q - 1) // 3, BLS_Q)
+    if bw6_lam.bit_length() > 320:
+        bw6_lam = bw6_lam * bw6_lam % BLS_Q
+    out.append(coeffs("Bw6G1Cfg", "Bw6Fq", 1, (0,), (BW6_Q - 1,), 0, glv2=(glv_beta_for(BW6_G1_XY, bw6_w, bw6_lam, BW6_Q), bw6_lam, BLS_Q)))
+    out.append(coeffs("Bw6G2Cfg", "Bw6Fq", 1, (0,), (4,), 0, glv2=(glv_beta_for(BW6_G2_XY, bw6_w, bw6_lam, BW6_Q), bw6_lam, BLS_Q)))
     out.append(coeffs("Mnt4G1Cfg", "Mnt4Fq", 1, (2,), (MNT4_B1,), 0))
     out.append(coeffs("Mnt4G2Cfg", "Mnt4Fq", 2, (26, 0), (0, MNT4_B1 * 13 % MNT_A), 13))
     out.append(coeffs("Mnt6G1Cfg", "Mnt6Fq", 1, (11,), (MNT6_B1,), 0))

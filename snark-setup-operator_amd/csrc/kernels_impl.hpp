@@ -246,6 +246,82 @@ PTAU_HD void glv_decompose(const uint32_t (&k)[8], uint32_t (&k1)[4], uint32_t (
     for (int i = 0; i < 4; i++) { k1[i] = rem[i]; k2[i] = qh[i]; }
 }
 
+// ---- small fixed-size big-integer helpers for the scalar decompositions (compile-time sizes, register arrays) ----
+template <int NA, int NB>
+PTAU_HD void bn_mul(const uint32_t (&a)[NA], const uint32_t (&b)[NB], uint32_t (&out)[NA + NB]) {
+#pragma unroll
+    for (int i = 0; i < NA + NB; i++) out[i] = 0;
+#pragma unroll
+    for (int i = 0; i < NA; i++) {
+        uint32_t carry = 0;
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+            const uint64_t t = (uint64_t)a[i] * b[j] + out[i + j] + carry;   // <= 2^64 - 1
+            out[i + j] = (uint32_t)t;
+            carry = (uint32_t)(t >> 32);
+        }
+        out[i + NB] = carry;
+    }
+}
+// acc (two's complement, N limbs) += sign * t (NT limbs, non-negative)
+template <int N, int NT>
+PTAU_HD void bn_addsub(uint32_t (&acc)[N], const uint32_t (&t)[NT], int sign) {
+    uint32_t c = 0;
+    if (sign > 0) {
+#pragma unroll
+        for (int i = 0; i < N; i++) acc[i] = addc(acc[i], i < NT ? t[i] : 0u, c);
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; i++) acc[i] = subb(acc[i], i < NT ? t[i] : 0u, c);
+    }
+}
+// |acc| -> out (low NO limbs), returns the sign
+template <int N, int NO>
+PTAU_HD bool bn_abs(uint32_t (&acc)[N], uint32_t (&out)[NO]) {
+    const bool neg = (acc[N - 1] >> 31) != 0;
+    if (neg) {
+        uint32_t c = 1;
+#pragma unroll
+        for (int i = 0; i < N; i++) acc[i] = addc(~acc[i], 0u, c);
+    }
+#pragma unroll
+    for (int i = 0; i < NO; i++) out[i] = acc[i];
+    return neg;
+}
+
+// Lattice GLV decomposition (BW6-761, both groups): k = k1 + k2 lambda (mod r), |k1|, |k2| < 2^191, signs returned.
+// c_i = (k G_i) >> 384 approximate the Babai rounding coefficients of the short basis (gen_constants.py checks the
+// bound over edge and random scalars).  Valid ONLY for points of the prime-order subgroup.
+template <class Cfg>
+PTAU_HD void glv2_decompose(const uint32_t (&k)[12], uint32_t (&k1)[6], uint32_t (&k2)[6], bool &neg1, bool &neg2) {
+    uint32_t g1[7], g2[7], a1[6], a2[6], b1[6], b2[6];
+#pragma unroll
+    for (int i = 0; i < 7; i++) { g1[i] = Cfg::GLV2_G1[i]; g2[i] = Cfg::GLV2_G2[i]; }
+#pragma unroll
+    for (int i = 0; i < 6; i++) { a1[i] = Cfg::GLV2_A1[i]; a2[i] = Cfg::GLV2_A2[i]; b1[i] = Cfg::GLV2_B1[i]; b2[i] = Cfg::GLV2_B2[i]; }
+    uint32_t p1[19], p2[19], c1[7], c2[7];
+    bn_mul<12, 7>(k, g1, p1);
+    bn_mul<12, 7>(k, g2, p2);
+#pragma unroll
+    for (int i = 0; i < 7; i++) { c1[i] = p1[12 + i]; c2[i] = p2[12 + i]; }
+    uint32_t t11[13], t12[13], t21[13], t22[13];
+    bn_mul<7, 6>(c1, a1, t11);
+    bn_mul<7, 6>(c2, a2, t12);
+    bn_mul<7, 6>(c1, b1, t21);
+    bn_mul<7, 6>(c2, b2, t22);
+    uint32_t acc[14];
+#pragma unroll
+    for (int i = 0; i < 14; i++) acc[i] = i < 12 ? k[i] : 0u;
+    bn_addsub<14, 13>(acc, t11, Cfg::GLV2_E11);
+    bn_addsub<14, 13>(acc, t12, Cfg::GLV2_E12);
+    neg1 = bn_abs<14, 6>(acc, k1);
+#pragma unroll
+    for (int i = 0; i < 14; i++) acc[i] = 0;
+    bn_addsub<14, 13>(acc, t21, Cfg::GLV2_E21);
+    bn_addsub<14, 13>(acc, t22, Cfg::GLV2_E22);
+    neg2 = bn_abs<14, 6>(acc, k2);
+}
+
 // 4-dimensional decomposition for BLS12 G2 (Galbraith-Scott): psi = twist^-1 o Frobenius o twist acts as [X] on the
 // prime-order subgroup and r = X^4 - X^2 + 1 < X^4, so the base-X digits of k, k = k0 + k1 X + k2 X^2 + k3 X^3 with
 // 0 <= k_j < X < 2^64, give k P = sum_j k_j psi^j(P): 64 doublings instead of 253.  Three restoring divisions by the
@@ -327,22 +403,26 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
     uint32_t k[NL];
     thread_scalar<Fr>(src, i, k);
     using Cfg = typename J::CfgT;
-    if constexpr (Cfg::HAS_GLV && NL == 8) {
+    if constexpr (Cfg::GLV_KIND != 0) {
         if (use_glv) {
-            // k = k1 + k2*lambda, k*P = k1*P + k2*phi(P), phi(X, Y, Z) = (beta X, Y, Z): 128-bit interleaved windows
-            uint32_t kk[2][4];
-            glv_decompose<Cfg>(k, kk[0], kk[1]);
+            // k = k1 + k2*lambda, k*P = k1*P + k2*phi(P), phi(X, Y, Z) = (beta X, Y, Z): two half-length scalars over
+            // ONE table, interleaved signed 4-bit windows.  HL = limbs of a half (128 bits BLS12-377, 192 bits BW6-761).
+            constexpr int HL = Cfg::GLV_KIND == 1 ? 4 : 6;
+            uint32_t kk[2][HL];
+            bool ng[2] = {false, false};
+            if constexpr (Cfg::GLV_KIND == 1) glv_decompose<Cfg>(k, kk[0], kk[1]);
+            else glv2_decompose<Cfg>(k, kk[0], kk[1], ng[0], ng[1]);
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 uint32_t c2 = 0;
 #pragma unroll
-                for (int j = 0; j < 4; j++) kk[h][j] = addc(kk[h][j], 0x88888888u, c2);   // k1, k2 < 2^126.2: no carry out
+                for (int j = 0; j < HL; j++) kk[h][j] = addc(kk[h][j], 0x88888888u, c2);   // halves < 2^(32 HL - 1): no carry out
             }
             F beta;
 #pragma unroll
             for (int j = 0; j < F::N; j++) beta.l[j] = Cfg::GLV_BETA[j];
             J acc = J::infinity();
-            for (int w = 31; w >= 0; w--) {
+            for (int w = HL * 8 - 1; w >= 0; w--) {
                 if (!acc.is_inf()) {
 #pragma nounroll
                     for (int d = 0; d < WINDOW_BITS; d++) acc = J::dbl(acc);
@@ -351,13 +431,13 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
                 for (int h = 0; h < 2; h++) {
                     uint32_t limb = 0;
 #pragma unroll
-                    for (int j = 0; j < 4; j++) limb = (j == (w >> 3)) ? (h ? kk[1][j] : kk[0][j]) : limb;
+                    for (int j = 0; j < HL; j++) limb = (j == (w >> 3)) ? (h ? kk[1][j] : kk[0][j]) : limb;
                     int dgt = (int)((limb >> ((w & 7) * 4)) & 15u) - 8;
                     if (dgt != 0) {
                         int mag = dgt < 0 ? -dgt : dgt;
                         J ent = wtab[(uint64_t)(mag - 1) * nslots + slot];
                         if (h) ent.X = F::mul(ent.X, beta);
-                        if (dgt < 0) ent.Y = F::neg(ent.Y);
+                        if ((dgt < 0) != (h ? ng[1] : ng[0])) ent.Y = F::neg(ent.Y);
                         acc = J::add(acc, ent);
                     }
                 }

@@ -296,7 +296,7 @@ def test_e2e_phase1_config1_files(pkg, cref, tmp_path):
         assert len(ch) == prm.accumulator_size and ch[:64].hex().startswith("786a02f742015903c6c6fd852552d272")
         assert open(f("challenge0.hash"), "rb").read() == pkg.calculate_hash(ch)
         for rnd in range(2):
-            key = pkg.PrivateKey(*keys[rnd], bytes(range(256)) * 5 + bytes(prm.public_key_size - 1280))
+            key = pkg.PrivateKey(*keys[rnd], (bytes(range(256)) * 12)[:prm.public_key_size])
             c, r, nc = f("challenge%d" % rnd), f("response%d" % rnd), f("challenge%d" % (rnd + 1))
             pkg.contribute(c, c + ".h", r, r + ".hash", pkg.CheckForCorrectness.No, pkg.BatchExpMode.Auto, prm, key)
             chal, resp = open(c, "rb").read(), open(r, "rb").read()

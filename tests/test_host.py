@@ -182,24 +182,26 @@ def test_endomorphism_subgroup_test_on_host(group):
     assert r.stdout == bytes([2])
 
 
-@pytest.mark.parametrize("group,n", [(1, 96), (2, 48)])
-def test_endomorphism_scalar_mul_bodies_on_host(group, n, cref):
-    """The GLV (G1, 2 x 128-bit) and GLS (G2, 4 x 64-bit, psi) window paths, run on the CPU by host_emul, against the
-    oracle's plain double-and-add on random subgroup points, for scalars c * tau^(start+i) at several offsets."""
+@pytest.mark.parametrize("name,group,n", [("bls12_377", 1, 96), ("bls12_377", 2, 48), ("bw6", 1, 40), ("bw6", 2, 40)])
+def test_endomorphism_scalar_mul_bodies_on_host(name, group, n, cref):
+    """The GLV (BLS12-377 G1, 2 x 128-bit), GLS (BLS12-377 G2, 4 x 64-bit, psi) and lattice-GLV (BW6-761 G1/G2,
+    2 x 192-bit signed) window paths, run on the CPU by host_emul, against the oracle's plain double-and-add on random
+    subgroup points, for scalars c * tau^(start+i) at several offsets — and the same with the endomorphism paths off."""
     import random
     from oracle.pyref import serde
     from oracle.pyref.ec import Group
     exe = os.path.join(ROOT, "tests", "native", "host_emul")
     if not os.path.exists(exe):
         pytest.skip("host_emul not built")
-    cv = CURVES["bls12_377"]
+    cv = CURVES[name]
+    cid = CURVE_NAMES.index(name)
     G = Group(cv, group)
     rng = random.Random(40 + group)
     pts = [G.mul(G.gen, rng.randrange(1, cv.r)) for _ in range(6)]
     data = serde.write_batch(G, [pts[i % 6] for i in range(n)], False)
     for start, tau, coeff in ((0, rng.randrange(cv.r), None), (12345, cv.r - 1, rng.randrange(cv.r)), (1 << 20, 2, None)):
-        exp = cref.apply_powers("bls12_377", group, data, n, start, tau, coeff, False, True)
-        args = ["apply", "0", str(group), str(n), str(start), "0", "1", "%x" % tau, "-" if coeff is None else "%x" % coeff]
+        exp = cref.apply_powers(name, group, data, n, start, tau, coeff, False, True, nthreads=8)
+        args = ["apply", str(cid), str(group), str(n), str(start), "0", "1", "%x" % tau, "-" if coeff is None else "%x" % coeff]
         r = subprocess.run([exe] + args, input=data, capture_output=True)
         assert r.returncode == 0 and r.stdout == exp
         r2 = subprocess.run([exe] + args, input=data, capture_output=True, env=dict(os.environ, PTAU_GLV="0"))
