@@ -210,10 +210,13 @@ def main():
         value = world * n * args.steps / dt
         kernel_s = (smul_ms / args.steps) / 1e3
         achieved = ALGO_BYTES_PER_UPDATE * n / kernel_s / 1e9
-        # parity spot check + CPU baseline on a bounded sample of the same chunk
-        sample = min(args.cpu_sample, n)
+        # parity check + CPU baseline on a bounded sample of the same chunk (the timed baseline only at N = 1: at
+        # N > 1 the other ranks would idle behind rank 0's host cores, so only a small parity sample is checked)
+        sample = min(args.cpu_sample if world == 1 else 4096, n)
         chal_host = d_chal[:sample * 96].cpu().numpy().tobytes()
         ref, base = cpu_baseline(sample, chal_host, start, tau)
+        if world > 1:
+            base = None
         got = d_resp[:sample * 48].cpu().numpy().tobytes()
         if got != ref:
             raise SystemExit("PARITY FAILURE: GPU response differs from the CPU oracle on the sampled points")

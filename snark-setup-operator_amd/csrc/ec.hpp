@@ -68,6 +68,27 @@ struct Jac {
         else return add_inl(p, q);
     }
 
+    // a * v for the curve coefficient a.  The MNT coefficients are small — a = 2 (MNT4 G1), 11 (MNT6 G1), 26 (MNT4 twist,
+    // in Fq), 11 u^2 (MNT6 twist) — so the product is a short addition chain (A_SMALL, A_SHIFT: a = A_SMALL * u^A_SHIFT)
+    // instead of a field multiplication in every doubling.
+    PTAU_HD static F mul_by_a(const F &v) {
+        if constexpr (Cfg::A_SMALL != 0) {
+            if constexpr (F::DEG == 1) {
+                return F::mul_small(v, Cfg::A_SMALL);
+            } else if constexpr (F::DEG == 2) {
+                static_assert(Cfg::A_SHIFT == 0, "Fq2 twist coefficient expected in the base field");
+                return F::make_pair_scaled(v, Cfg::A_SMALL);
+            } else {
+                static_assert(Cfg::A_SHIFT == 2, "Fq3 twist coefficient expected as A_SMALL u^2");
+                using B = typename F::Base;   // (c0, c1, c2) u^2 = (NR c1, NR c2, c0)
+                return F::make(B::mul_small(B::mul_small(v.c1, Cfg::NR), Cfg::A_SMALL),
+                               B::mul_small(B::mul_small(v.c2, Cfg::NR), Cfg::A_SMALL), B::mul_small(v.c0, Cfg::A_SMALL));
+            }
+        } else {
+            return F::mul(CurveConsts<F, Cfg>::coeff_a(), v);
+        }
+    }
+
     // dbl-2009-l (a = 0) / dbl-2007-bl (general a)
     PTAU_HD static Jac dbl_inl(const Jac &p) {
         if (p.is_inf()) return p;
@@ -79,7 +100,7 @@ struct Jac {
         F M = F::add(F::dbl(XX), XX);
         if constexpr (!Cfg::A_IS_ZERO) {
             F ZZ = F::sqr(p.Z);
-            M = F::add(M, F::mul(CurveConsts<F, Cfg>::coeff_a(), F::sqr(ZZ)));
+            M = F::add(M, mul_by_a(F::sqr(ZZ)));
         }
         Jac r;
         r.Z = F::dbl(F::mul(p.Y, p.Z));

@@ -58,6 +58,7 @@ struct Fp2 {
     }
     PTAU_HD static Fp2 mul_base(const Fp2 &a, const F &k) { return {F::mul(a.c0, k), F::mul(a.c1, k)}; }
     PTAU_HD static Fp2 make(const F &c0, const F &c1) { return {c0, c1}; }
+    PTAU_HD static Fp2 make_pair_scaled(const Fp2 &a, int k) { return {F::mul_small(a.c0, k), F::mul_small(a.c1, k)}; }
     PTAU_HD static Fp2 conj(const Fp2 &a) { return {a.c0, F::neg(a.c1)}; }
     static constexpr int LANES = 1;   // lanes of a wavefront that hold one element
     __host__ __device__ __noinline__ static Fp2 inverse(const Fp2 &a) {
@@ -167,6 +168,7 @@ struct Fp2L {
     PTAU_HD static Fp2L dbl(const Fp2L &a) { return {F::dbl(a.c)}; }
     PTAU_HD static Fp2L conj(const Fp2L &a) { return {lane_parity() ? F::neg(a.c) : a.c}; }
     PTAU_HD static Fp2L mul_base(const Fp2L &a, const F &k) { return {F::mul(a.c, k)}; }
+    PTAU_HD static Fp2L make_pair_scaled(const Fp2L &a, int k) { return {F::mul_small(a.c, k)}; }
     // even: a0 b0 + NR a1 b1      odd: a1 b0 + a0 b1
     PTAU_HD static Fp2L mul(const Fp2L &a, const Fp2L &b) {
         const bool odd = lane_parity() != 0;

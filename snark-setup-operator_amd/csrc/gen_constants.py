@@ -224,6 +224,10 @@ def main():
             s.append("  static constexpr uint32_t GLV_M[5] = {%s};" % limbs((1 << 256) // lam, 5))
         s.append("  static constexpr int DEG = %d;" % deg)
         s.append("  static constexpr bool A_IS_ZERO = %s;" % ("true" if not any(a) else "false"))
+        # a = A_SMALL * u^A_SHIFT when exactly one coefficient is set and small (doubling uses an addition chain)
+        nzc = [(i, v) for i, v in enumerate(a) if v]
+        small = len(nzc) == 1 and nzc[0][1] < 64
+        s.append("  static constexpr int A_SMALL = %d, A_SHIFT = %d;" % ((nzc[0][1], nzc[0][0]) if small else (0, 0)))
         s.append("  static constexpr int NR = %d;   // u^DEG = NR (small signed int)" % nr)
         for i in range(deg):
             s.append("  static constexpr uint32_t A%d[%d] = {%s};" % (i, n, limbs(mont(a[i], p, R), n)))
