@@ -141,12 +141,22 @@ int errbits_to_code(int bits, const Err &err) {
     return err.fail(PTAU_E_NOT_IN_SUBGROUP, "element is not in the prime-order subgroup");
 }
 
+int run_subgroup_check_dev(DeviceCtx *c, int curve, int group, const GroupOps *ops, const uint8_t *d_in, int cin, uint64_t n,
+                           const Err &err);
+
 // One vector on device-resident buffers; caller holds the device mutex and has set the device.
-int run_apply_powers_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, int cin, uint8_t *d_out, int cout,
+// check_input (setup_utils::CheckForCorrectness): bit 0 = non-zero, bit 1 = in the prime-order subgroup (and on the curve)
+// — the second runs the membership kernels over the whole vector first, which is also what makes the endomorphism
+// (GLV / GLS) paths exact: they assume subgroup elements, as every element of a verified challenge is.
+int run_apply_powers_dev(DeviceCtx *c, int curve, int group, const GroupOps *ops, const uint8_t *d_in, int cin, uint8_t *d_out, int cout,
                          uint64_t n, uint64_t start, const uint64_t *tau, const uint64_t *coeff, int check_input,
                          const Err &err) {
     const int isz = cin ? ops->comp : ops->uncomp, osz = cout ? ops->comp : ops->uncomp;
     std::vector<uint32_t> table((1 + ptau::SCALAR_TABLE_ENTRIES) * ops->fr_limbs32);
+    if (check_input & 2) {
+        int rc = run_subgroup_check_dev(c, curve, group, ops, d_in, cin, n, err);
+        if (rc) return rc;
+    }
     const bool windowed = use_window_kernel();
     const uint64_t launch_cap = windowed
         ? std::max<uint64_t>(256, std::min(MAX_LAUNCH_POINTS, MAX_WINDOW_TABLE_BYTES / (ptau::WINDOW_ENTRIES * ops->jac_bytes)))
@@ -188,7 +198,7 @@ int run_apply_powers_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in,
     return PTAU_OK;
 }
 
-int run_apply_powers_host(DeviceCtx *c, const GroupOps *ops, const uint8_t *in, int cin, uint8_t *out, int cout, uint64_t n,
+int run_apply_powers_host(DeviceCtx *c, int curve, int group, const GroupOps *ops, const uint8_t *in, int cin, uint8_t *out, int cout, uint64_t n,
                           uint64_t start, const uint64_t *tau, const uint64_t *coeff, int check_input, const Err &err) {
     const size_t isz = cin ? ops->comp : ops->uncomp, osz = cout ? ops->comp : ops->uncomp;
     if (!n) return PTAU_OK;
@@ -202,7 +212,7 @@ int run_apply_powers_host(DeviceCtx *c, const GroupOps *ops, const uint8_t *in, 
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
     c->timing.h2d_ms += ms;
-    if ((rc = run_apply_powers_dev(c, ops, (const uint8_t *)c->d_in, cin, (uint8_t *)c->d_out, cout, n, start, tau, coeff,
+    if ((rc = run_apply_powers_dev(c, curve, group, ops, (const uint8_t *)c->d_in, cin, (uint8_t *)c->d_out, cout, n, start, tau, coeff,
                                    check_input, err)))
         return rc;
     HIP_TRY(hipEventRecord(c->ev[3], c->stream));
@@ -737,7 +747,7 @@ int ptau_apply_powers_dev(int curve, int group, const void *d_in, int compressed
     std::lock_guard<std::mutex> lk(c->mu);
     HIP_TRY(hipSetDevice(device));
     c->timing = ptau_timing{};
-    return run_apply_powers_dev(c, ops, (const uint8_t *)d_in, compressed_in, (uint8_t *)d_out, compressed_out, n, start, tau,
+    return run_apply_powers_dev(c, curve, group, ops, (const uint8_t *)d_in, compressed_in, (uint8_t *)d_out, compressed_out, n, start, tau,
                                 coeff, check_input, err);
 }
 
@@ -754,7 +764,7 @@ int ptau_apply_powers(int curve, int group, const uint8_t *in, int compressed_in
     std::lock_guard<std::mutex> lk(c->mu);
     HIP_TRY(hipSetDevice(device));
     c->timing = ptau_timing{};
-    return run_apply_powers_host(c, ops, in, compressed_in, out, compressed_out, n, start, tau, coeff, check_input, err);
+    return run_apply_powers_host(c, curve, group, ops, in, compressed_in, out, compressed_out, n, start, tau, coeff, check_input, err);
 }
 
 int ptau_phase1_computation(const ptau_params *p, const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len,
@@ -782,16 +792,16 @@ int ptau_phase1_computation(const ptau_params *p, const uint8_t *in, size_t in_l
     const uint8_t *pi = in + 64;
     uint8_t *po = out + 64;
     // tauG1 | tauG2 | alphaG1 | betaG1 | betaG2  (SURVEY App. A.1); exponent index is global: start + i
-    if ((rc = run_apply_powers_host(c, g1, pi, 0, po, 1, n1, s, tau, nullptr, check_input, err))) return rc;
+    if ((rc = run_apply_powers_host(c, p->curve, 1, g1, pi, 0, po, 1, n1, s, tau, nullptr, check_input, err))) return rc;
     pi += n1 * g1->uncomp; po += n1 * g1->comp;
-    if ((rc = run_apply_powers_host(c, g2, pi, 0, po, 1, n2, s, tau, nullptr, check_input, err))) return rc;
+    if ((rc = run_apply_powers_host(c, p->curve, 2, g2, pi, 0, po, 1, n2, s, tau, nullptr, check_input, err))) return rc;
     pi += n2 * g2->uncomp; po += n2 * g2->comp;
-    if ((rc = run_apply_powers_host(c, g1, pi, 0, po, 1, n2, s, tau, alpha, check_input, err))) return rc;
+    if ((rc = run_apply_powers_host(c, p->curve, 1, g1, pi, 0, po, 1, n2, s, tau, alpha, check_input, err))) return rc;
     pi += n2 * g1->uncomp; po += n2 * g1->comp;
-    if ((rc = run_apply_powers_host(c, g1, pi, 0, po, 1, n2, s, tau, beta, check_input, err))) return rc;
+    if ((rc = run_apply_powers_host(c, p->curve, 1, g1, pi, 0, po, 1, n2, s, tau, beta, check_input, err))) return rc;
     pi += n2 * g1->uncomp; po += n2 * g1->comp;
     // betaG2 <- beta * betaG2 : tau^0 with coefficient beta
-    return run_apply_powers_host(c, g2, pi, 0, po, 1, 1, 0, tau, beta, check_input, err);
+    return run_apply_powers_host(c, p->curve, 2, g2, pi, 0, po, 1, 1, 0, tau, beta, check_input, err);
 }
 
 int ptau_contribute_file(const ptau_params *p, const char *challenge_path, const char *challenge_hash_path,

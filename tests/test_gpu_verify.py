@@ -329,3 +329,28 @@ def test_e2e_phase1_config1_files(pkg, cref, tmp_path):
     t = keys[0][0] * keys[1][0] % CURVES[name].r
     G1 = Group(CURVES[name], 1)
     assert combined[64 + 96:64 + 192] == serde.write_point(G1, G1.mul(G1.gen, t), False)
+
+
+@pytest.mark.parametrize("name,group", [("bls12_377", 1), ("bls12_377", 2), ("bw6", 1)])
+def test_contribute_check_input_in_group(name, group, pkg, cref):
+    """CheckForCorrectness on the contribute side (--force-correctness-checks upgrades it to Full, contribute.rs:129-133):
+    OnlyInGroup / Full run the membership test over the input vector before the update and reject a curve point outside
+    the prime-order subgroup; with No (the operator's default) a vector of subgroup points gives the oracle's bytes."""
+    c = CURVES[name]
+    G = Group(c, group)
+    rng = random.Random(8)
+    good = [G.mul(G.gen, rng.randrange(1, c.r)) for _ in range(6)]
+    tau = rng.randrange(c.r)
+    data = serde.write_batch(G, good, False)
+    exp = cref.apply_powers(name, group, data, 6, 3, tau, None, False, True)
+    for chk in (pkg.CheckForCorrectness.No, pkg.CheckForCorrectness.Full):
+        assert pkg.phase1_cli.apply_powers(name, group, data, 6, 3, tau, check_input=chk) == exp
+    bad = serde.write_batch(G, good[:2] + [_off_subgroup_point(G, rng)] + good[2:], False)
+    for chk in (pkg.CheckForCorrectness.OnlyInGroup, pkg.CheckForCorrectness.Full):
+        with pytest.raises(pkg.PtauError) as e:
+            pkg.phase1_cli.apply_powers(name, group, bad, 7, 3, tau, check_input=chk)
+        assert e.value.code == -5
+    inf = serde.write_batch(G, good[:1] + [None], False)
+    with pytest.raises(pkg.PtauError) as e:
+        pkg.phase1_cli.apply_powers(name, group, inf, 2, 0, tau, check_input=pkg.CheckForCorrectness.OnlyNonZero)
+    assert e.value.code == -4
