@@ -152,12 +152,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    # rehearsal knobs for a one-GPU box (the driver's N > 1 runs use neither): PTAU_BENCH_BACKEND=gloo lets several ranks
+    # share one device (RCCL refuses duplicate GPUs), PTAU_BENCH_DEVICE pins every rank to that device
+    backend = os.environ.get("PTAU_BENCH_BACKEND", "nccl")
+    if "PTAU_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["PTAU_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     pkg = load_pkg()
     L = pkg.load_library()
@@ -202,7 +210,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
