@@ -16,6 +16,9 @@
 
 #include "ec.hpp"
 
+#ifndef PTAU_G1_MIN_WAVES
+#define PTAU_G1_MIN_WAVES 2
+#endif
 #ifndef PTAU_LANE_MIN_WAVES
 #define PTAU_LANE_MIN_WAVES 2
 #endif
@@ -44,11 +47,12 @@ struct GroupTypes {
     using A = Affine<F>;
     static constexpr int COMP = F::BYTES;
     static constexpr int UNCOMP = 2 * F::BYTES;
-    // Waves per SIMD the kernels are compiled for (0 = the compiler's choice; lane-pair groups inline everything and
-    // are held to 256 registers = two waves).  Point operations over the wide fields
+    // Waves per SIMD the kernels are compiled for (0 = the compiler's choice).  Groups whose point operations are
+    // inlined (12-limb G1, lane-pair G2) are held to 256 registers = two waves: left alone, the membership kernel of
+    // BLS12-377 G1 took 494 (VGPRs + AGPRs) and ran one wave per SIMD.  Point operations over the wide fields
     // take all 512 unified registers (256 VGPRs + 256 AGPRs) and run ONE wave per SIMD; the bound only reaches the
     // kernel body, not its out-of-line callees, so it is off by default (-DPTAU_MIN_WAVES_WIDE=2 for experiments).
-    static constexpr int MIN_WAVES = LPP == 2 ? PTAU_LANE_MIN_WAVES : (PTAU_MIN_WAVES_WIDE > 0 && sizeof(F) > 48 ? PTAU_MIN_WAVES_WIDE : 1);
+    static constexpr int MIN_WAVES = LPP == 2 ? PTAU_LANE_MIN_WAVES : sizeof(F) <= 48 ? PTAU_G1_MIN_WAVES : (PTAU_MIN_WAVES_WIDE > 0 && sizeof(F) > 48 ? PTAU_MIN_WAVES_WIDE : 1);
 };
 
 // table layout: [0] = base coefficient c*tau^start, [1+k] = tau^(2^k); all Montgomery, Fr::N limbs
@@ -867,12 +871,12 @@ PTAU_HD int endo_subgroup_thread(const uint8_t *in, int compressed_in, uint64_t 
     const bool ok = (t.X == F::mul(ex, zz)) && (t.Y == F::mul(ey, F::mul(zz, t.Z)));
     return ok ? 0 : ERRBIT_NOT_IN_SUBGROUP;
 }
-template <class G>
+template <class G, int CIN>
 __global__ void __launch_bounds__(256, G::MIN_WAVES)
-endo_subgroup_kernel(const uint8_t *__restrict__ in, int compressed_in, uint64_t n, int *__restrict__ err) {
+endo_subgroup_kernel(const uint8_t *__restrict__ in, uint64_t n, int *__restrict__ err) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    int bad = endo_subgroup_thread<G>(in, compressed_in, i);
+    int bad = endo_subgroup_thread<G>(in, CIN, i);
     if (bad) atomicOr(err, bad);
 }
 
@@ -1143,7 +1147,8 @@ struct Launch {
     static void endo_subgroup(hipStream_t s, const uint8_t *in, int cin, uint64_t n, int *err) {
         if constexpr (G::J::CfgT::ENDO_KIND != 0) {
             if (!n) return;
-            hipLaunchKernelGGL(endo_subgroup_kernel<G>, grid(n), dim3(256), 0, s, in, cin, n, err);
+            if (cin) hipLaunchKernelGGL((endo_subgroup_kernel<G, 1>), grid(n), dim3(256), 0, s, in, n, err);
+            else hipLaunchKernelGGL((endo_subgroup_kernel<G, 0>), grid(n), dim3(256), 0, s, in, n, err);
         }
     }
     static void decompress(hipStream_t s, const uint8_t *in, uint8_t *out, uint64_t n, int check_nonzero, int *err) {
