@@ -182,10 +182,12 @@ struct Fp2L {
         const bool odd = lane_parity() != 0;
         const F ao = other(a.c);
         const F l = sel(odd, ao, F::add(a.c, ao));
-        const F r = sel(odd, a.c, F::add(a.c, F::mul_small(ao, NR)));
+        // a0 + NR a1 and t - (1 + NR) v as the shortest chains: for NR = -5 that is a0 - 5 a1 and t + 4 v
+        const F nra = NR < 0 ? F::sub(a.c, F::mul_small(ao, -NR)) : F::add(a.c, F::mul_small(ao, NR));
+        const F r = sel(odd, a.c, nra);
         const F t = F::mul(l, r);
         const F v = other(t);                            // even lanes receive v = a0 a1
-        const F even = F::sub(F::sub(t, v), F::mul_small(v, NR));
+        const F even = (1 + NR) <= 0 ? F::add(t, F::mul_small(v, -(1 + NR))) : F::sub(t, F::mul_small(v, 1 + NR));
         return {sel(odd, F::dbl(t), even)};
     }
     __device__ __noinline__ static Fp2L inverse(const Fp2L &a) {

@@ -23,7 +23,7 @@
 #define PTAU_LANE_MIN_WAVES 2
 #endif
 #ifndef PTAU_MIN_WAVES_WIDE
-#define PTAU_MIN_WAVES_WIDE 0
+#define PTAU_MIN_WAVES_WIDE 2
 #endif
 
 namespace ptau {
@@ -50,8 +50,9 @@ struct GroupTypes {
     // Waves per SIMD the kernels are compiled for (0 = the compiler's choice).  Groups whose point operations are
     // inlined (12-limb G1, lane-pair G2) are held to 256 registers = two waves: left alone, the membership kernel of
     // BLS12-377 G1 took 494 (VGPRs + AGPRs) and ran one wave per SIMD.  Point operations over the wide fields
-    // take all 512 unified registers (256 VGPRs + 256 AGPRs) and run ONE wave per SIMD; the bound only reaches the
-    // kernel body, not its out-of-line callees, so it is off by default (-DPTAU_MIN_WAVES_WIDE=2 for experiments).
+    // go through out-of-line callees the bound does not reach (single-lane Fq2 / Fq3 callees keep their 512 registers and
+    // one wave per SIMD), but the 24-limb prime-field groups' callees fit 248 VGPRs, so bounding the kernel body (276
+    // otherwise) is what gets BW6-761 and MNT G1 to two waves.
     static constexpr int MIN_WAVES = LPP == 2 ? PTAU_LANE_MIN_WAVES : sizeof(F) <= 48 ? PTAU_G1_MIN_WAVES : (PTAU_MIN_WAVES_WIDE > 0 && sizeof(F) > 48 ? PTAU_MIN_WAVES_WIDE : 1);
 };
 

@@ -190,3 +190,35 @@ def test_full_size_bls12_377_tau_g1(pkg, cref):
     v2 = pkg.phase1_cli.apply_powers(name, 1, v1u, n, 0, b, None, False, True)
     v12 = pkg.phase1_cli.apply_powers(name, 1, v0, n, 0, a * b % c.r, None, False, True)
     assert pkg.calculate_hash(v2) == pkg.calculate_hash(v12)
+
+
+@pytest.mark.parametrize("name,group,log2n", [("bls12_377", 1, 20), ("bls12_377", 2, 20), ("bw6", 1, 18), ("bw6", 2, 18),
+                                              ("mnt4_753", 1, 16), ("mnt4_753", 2, 14), ("mnt6_753", 1, 16), ("mnt6_753", 2, 13)])
+def test_full_size_round_trip(name, group, log2n, pkg, cref):
+    """BASELINE-size vectors (configs 2-4: 2^20 BLS12-377, 2^18 BW6-761, 2^16 MNT G1) through size-independent properties:
+    a tau-update followed by the tau^-1-update at the same offset is the identity on the bytes, compressed output is the
+    uncompressed output with y dropped (same x bytes, flags moved), and the first / last 128 elements are bit-exact
+    vs the C oracle."""
+    from oracle.pyref import serde
+    from oracle.pyref.curves import CURVES
+    from oracle.pyref.ec import Group
+    c = CURVES[name]
+    G = Group(c, group)
+    n, start = 1 << log2n, 3 * (1 << log2n)
+    u, cs = G.uncomp_size, G.comp_size
+    s, tau = 0x1234567890abcdef1234567890abcdef % c.r, (c.r // 7) * 3 + 11
+    gen = serde.write_point(G, G.gen, False) * n
+    v = pkg.phase1_cli.apply_powers(name, group, gen, n, 0, s, None, False, False)          # a genuine accumulator vector
+    w = pkg.phase1_cli.apply_powers(name, group, v, n, start, tau, None, False, False)
+    back = pkg.phase1_cli.apply_powers(name, group, w, n, start, pow(tau, -1, c.r), None, False, False)
+    assert back == v
+    wc = pkg.phase1_cli.apply_powers(name, group, v, n, start, tau, None, False, True)
+    fb = c.fq_bytes
+    for i in (0, 1, n // 2, n - 1):                      # compressed = x bytes of the uncompressed form, sign flag from y
+        xu, xc = bytearray(w[i * u:i * u + cs]), bytearray(wc[i * cs:(i + 1) * cs])
+        flag = w[i * u + u - 1] & 0x80
+        xu[-1] |= flag
+        assert xu == xc
+    k = 128
+    assert w[:k * u] == cref.apply_powers(name, group, v[:k * u], k, start, tau, None, False, False, nthreads=8)
+    assert w[-k * u:] == cref.apply_powers(name, group, v[-k * u:], k, start + n - k, tau, None, False, False, nthreads=8)
