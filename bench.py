@@ -131,6 +131,24 @@ def whole_chunk_extras(pkg, log2n, dev):
                                                "(PCIe both ways), public key + BLAKE2b(response) + msync",
                                    "device_ms": tm["kernel_ms"], "h2d_ms": tm["h2d_ms"], "d2h_ms": tm["d2h_ms"]}
         assert open(f("c1"), "rb").read(64) == open(f("v.r.hash"), "rb").read()   # new challenge extends the response it verified
+        # whole-transcript tail (BASELINE configs[4]: verify_transcript's combine + transform_ratios): the round's second
+        # chunk (tauG1 only, 2^n - 1 elements) contributed with the same key, both responses combined, ratio checks run
+        prm1 = pkg.Phase1Parameters.new_chunk("bls12_377", 0, 1, n, 0, log2n, n)
+        full = pkg.Phase1Parameters.new_full("bls12_377", 0, log2n, n)
+        pkg.new_challenge(f("d0"), f("d0.hash"), prm1)
+        pkg.contribute(f("d0"), f("d0.hash2"), f("s0"), f("s0.hash"), pkg.CheckForCorrectness.No, pkg.BatchExpMode.Auto, prm1,
+                       pkg.PrivateKey(*k0, bytes(prm1.public_key_size)), device=dev)
+        responses = [open(f("r0"), "rb").read(), open(f("s0"), "rb").read()]
+        t0 = time.perf_counter()
+        combined = pkg.combine(responses, n, full, device=dev)
+        dt4 = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        pkg.transform_ratios(combined, pkg.CheckForCorrectness.No, full, device=dev)
+        dt5 = time.perf_counter() - t0
+        out["transcript_tail"] = {"combine_seconds": dt4, "transform_ratios_seconds": dt5, "combined_bytes": len(combined),
+                                  "includes": "combine: sqrt decompression of both chunk responses into the Full-mode accumulator; "
+                                              "transform_ratios: power_pairs (bucket MSM) over tauG1 (2^%d - 1), tauG2, alphaG1, betaG1 "
+                                              "(2^%d each) + 5 pairing checks; host buffers" % (log2n + 1, log2n)}
     finally:
         shutil.rmtree(d, ignore_errors=True)
     return out

@@ -286,7 +286,6 @@ int run_msm_bucket_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, i
     const int scalar_bits = src.mode == ptau::SCALAR_PRF ? ptau::PRF_BITS : ops->fr_bits;
     const uint64_t nslice = n ? (n + MSM_SLICE_POINTS - 1) / MSM_SLICE_POINTS : 1;
     const uint64_t cap = std::min<uint64_t>(std::max<uint64_t>(n, 1), MSM_SLICE_POINTS);
-    const ptau::MsmPlan big = msm_plan(cap, scalar_bits);
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     // workspace carve-up (sized for the largest slice; W*B peaks at the largest c)
     size_t wb_max = 0, w_max = 0;
@@ -295,7 +294,6 @@ int run_msm_bucket_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, i
         wb_max = std::max(wb_max, (size_t)pl.W * pl.B);
         w_max = std::max(w_max, (size_t)pl.W);
     }
-    (void)big;
     const size_t sz_aff = al((cap + 1) * ops->affine_bytes), sz_dig = al(w_max * cap * 4), sz_sorted = sz_dig,
                  sz_counts = al(wb_max * 4), sz_offsets = al((wb_max + 1) * 4), sz_buckets = al(nsum * wb_max * ops->jac_bytes),
                  sz_parts = sz_buckets, sz_totals = al((nsum * (nslice + 1) + 8) * ops->jac_bytes),

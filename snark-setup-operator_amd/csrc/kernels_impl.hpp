@@ -881,38 +881,6 @@ endo_subgroup_kernel(const uint8_t *__restrict__ in, uint64_t n, int *__restrict
     if (bad) atomicOr(err, bad);
 }
 
-// Scalar multiplication of every point by ONE public scalar of `nbits` bits (subgroup check with
-// the group order, cofactor clearing): result Jacobian to scratch.
-template <class G>
-PTAU_HD int fixed_scalar_mul_thread(const uint8_t *in, int compressed_in, typename G::J *scratch, uint64_t i,
-                                    const uint32_t *scalar, int nbits) {
-    using A = typename G::A;
-    using J = typename G::J;
-    A p;
-    int bad = read_point_any<G>(in, compressed_in, i, p);
-    if (bad) {
-        scratch[i] = J::infinity();
-        return bad;
-    }
-    J acc = J::infinity();
-    for (int b = nbits - 1; b >= 0; b--) {
-        acc = J::dbl(acc);
-        if ((scalar[b >> 5] >> (b & 31)) & 1u) acc = J::add_mixed(acc, p);   // wave-uniform branch
-    }
-    scratch[i] = acc;
-    return 0;
-}
-
-template <class G>
-__global__ void __launch_bounds__(256, G::MIN_WAVES)
-fixed_scalar_mul_kernel(const uint8_t *__restrict__ in, int compressed_in, typename G::J *__restrict__ scratch,
-                        uint64_t n, const uint32_t *__restrict__ scalar, int nbits, int *__restrict__ err) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int bad = fixed_scalar_mul_thread<G>(in, compressed_in, scratch, i, scalar, nbits);
-    if (bad) atomicOr(err, bad);
-}
-
 // Batched normalisation + serialisation.  Thread t owns elements t, t+T, t+2T, ... (< n).
 template <class G>
 PTAU_HD int normalize_thread(const typename G::J *scratch, typename G::F *pre, uint8_t *out, int compressed_out,
@@ -1021,8 +989,6 @@ struct GroupOps {
     void (*reduce_rows)(hipStream_t, const void *in, void *out, uint32_t rows, uint32_t cols, uint32_t T);
     void (*msm_horner)(hipStream_t, const void *win, void *out, MsmPlan pl);
     void (*on_curve)(hipStream_t, const uint8_t *in, uint64_t n, int *err);
-    void (*fixed_scalar_mul)(hipStream_t, const uint8_t *in, int cin, void *scratch, uint64_t n,
-                             const uint32_t *scalar, int nbits, int *err);
     void (*normalize)(hipStream_t, const void *scratch, void *pre, uint8_t *out, int cout, uint64_t n, uint64_t T,
                       int check_nonzero, int *err);
     void (*expect_infinity)(hipStream_t, const void *scratch, uint64_t n, int *err);
@@ -1129,12 +1095,6 @@ struct Launch {
         if (!n) return;
         hipLaunchKernelGGL(on_curve_kernel<G>, grid(n), dim3(256), 0, s, in, n, err);
     }
-    static void fixed_scalar_mul(hipStream_t s, const uint8_t *in, int cin, void *scratch, uint64_t n,
-                                 const uint32_t *scalar, int nbits, int *err) {
-        if (!n) return;
-        hipLaunchKernelGGL(fixed_scalar_mul_kernel<G>, grid(n), dim3(256), 0, s, in, cin, (typename G::J *)scratch, n,
-                           scalar, nbits, err);
-    }
     static void normalize(hipStream_t s, const void *scratch, void *pre, uint8_t *out, int cout, uint64_t n, uint64_t T,
                           int check_nonzero, int *err) {
         if (!n) return;
@@ -1181,7 +1141,6 @@ struct Launch {
         o.msm_bucket_reduce = msm_bucket_reduce;
         o.reduce_rows = reduce_rows;
         o.msm_horner = msm_horner;
-        o.fixed_scalar_mul = fixed_scalar_mul;
         o.normalize = normalize;
         o.expect_infinity = expect_infinity;
         o.endo_subgroup = G::J::CfgT::ENDO_KIND != 0 ? endo_subgroup : nullptr;
