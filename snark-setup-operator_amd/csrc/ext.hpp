@@ -154,7 +154,12 @@ struct Fp2L {
         for (int i = 0; i < F::N; i++) r.l[i] = odd ? if_odd.l[i] : if_even.l[i];
         return r;
     }
-    PTAU_HD static bool both(bool mine) { return mine && (lane_xchg(mine ? 1u : 0u) != 0u); }
+    // NB every exchange is executed unconditionally by both lanes of a pair: a DPP move issued under a lane-divergent
+    // condition would read its partner while that lane is masked off.
+    PTAU_HD static bool both(bool mine) {
+        const uint32_t theirs = lane_xchg(mine ? 1u : 0u);
+        return mine && theirs != 0u;
+    }
 
     PTAU_HD static Fp2L make(const F &c0, const F &c1) { return {lane_parity() ? c1 : c0}; }
     PTAU_HD static Fp2L zero() { return {F::zero()}; }
@@ -204,7 +209,8 @@ struct Fp2L {
         const bool odd = lane_parity() != 0;
         uint8_t fl = 0;
         bool ok = F::read_bytes(in + (odd ? F::BYTES : 0), with_flags && odd, &fl, out.c);
-        if (with_flags) *flags = (uint8_t)(odd ? fl : lane_xchg(fl));   // the flag bits sit in the last byte of a1
+        const uint32_t fl_other = lane_xchg((uint32_t)fl);
+        if (with_flags) *flags = (uint8_t)(odd ? (uint32_t)fl : fl_other);   // the flag bits sit in the last byte of a1
         return both(ok);
     }
     PTAU_HD void write_bytes(uint8_t *out, uint8_t flags) const {

@@ -691,6 +691,26 @@ msm_scatter_kernel(const uint32_t *__restrict__ dig, uint32_t *__restrict__ curs
 //   msm_combine    : one thread per bucket — sums the bucket's run partials (one or two for a balanced window).
 constexpr uint32_t MSM_RUN = 64;
 
+// Affine point `idx` of an array written in the STANDARD (single-lane) layout — Affine<Fp2> = x.c0 x.c1 y.c0 y.c1 inf —
+// as the group's own Affine (lane-pair groups pick their coefficient).
+template <class G>
+PTAU_HD typename G::A load_affine_std(const typename G::A *aff, uint64_t idx) {
+    if constexpr (G::LPP == 2) {
+        using Fq = typename G::Fq;
+        constexpr size_t STRIDE = 4 * sizeof(Fq) + sizeof(uint32_t);   // sizeof(Affine<Fp2<Fq>>): 4 coefficients + flag word
+        static_assert(sizeof(Affine<Fp2<Fq, 1>>) == STRIDE, "standard affine layout changed");
+        const uint8_t *base = reinterpret_cast<const uint8_t *>(aff) + idx * STRIDE;
+        const Fq *c = reinterpret_cast<const Fq *>(base);
+        typename G::A q;
+        q.x.c = c[lane_parity()];
+        q.y.c = c[2 + lane_parity()];
+        q.inf = *reinterpret_cast<const bool *>(base + 4 * sizeof(Fq));
+        return q;
+    } else {
+        return aff[idx];
+    }
+}
+
 template <class G>
 PTAU_HD void msm_accumulate_thread(const typename G::A *aff, const uint32_t *sorted, const uint32_t *offsets,
                                    const uint32_t *run_offsets, typename G::J *partials, uint32_t shift,
@@ -709,18 +729,18 @@ PTAU_HD void msm_accumulate_thread(const typename G::A *aff, const uint32_t *sor
     J acc = J::infinity();
     for (uint32_t e = e0; e < e1; e++) {
         const uint32_t s = sorted[e];
-        typename G::A q = aff[(uint64_t)(s & 0x7fffffffu) + shift];
+        typename G::A q = load_affine_std<G>(aff, (uint64_t)(s & 0x7fffffffu) + shift);
         if (s >> 31) q.y = F::neg(q.y);
         acc = J::add_mixed(acc, q);
     }
-    partials[v] = acc;
+    store_jac<G>(partials, v, acc);
 }
 template <class G>
 __global__ void __launch_bounds__(256, G::MIN_WAVES)
 msm_accumulate_kernel(const typename G::A *__restrict__ aff, const uint32_t *__restrict__ sorted,
                       const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ run_offsets,
                       typename G::J *__restrict__ partials, uint32_t shift, uint32_t total_buckets) {
-    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t v = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G::LPP;
     if (v >= run_offsets[total_buckets]) return;   // the grid is sized for the worst case, the run count lives on the device
     msm_accumulate_thread<G>(aff, sorted, offsets, run_offsets, partials, shift, total_buckets, (uint32_t)v);
 }
@@ -875,7 +895,7 @@ PTAU_HD int endo_subgroup_thread(const uint8_t *in, int compressed_in, uint64_t 
 template <class G, int CIN>
 __global__ void __launch_bounds__(256, G::MIN_WAVES)
 endo_subgroup_kernel(const uint8_t *__restrict__ in, uint64_t n, int *__restrict__ err) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G::LPP;
     if (i >= n) return;
     int bad = endo_subgroup_thread<G>(in, CIN, i);
     if (bad) atomicOr(err, bad);
@@ -1072,6 +1092,13 @@ struct Launch {
     }
     static void msm_accumulate(hipStream_t s, const void *aff, const uint32_t *sorted, const uint32_t *offsets,
                                const uint32_t *run_offsets, void *partials, uint32_t shift, uint32_t total_buckets, uint64_t max_runs) {
+        if constexpr (!std::is_void_v<GL>) {
+            if (lane_pair_enabled()) {   // two threads per run; affine input and Jacobian partials in G's layouts
+                hipLaunchKernelGGL(msm_accumulate_kernel<GL>, grid(max_runs * 2), dim3(256), 0, s, (const typename GL::A *)aff,
+                                   sorted, offsets, run_offsets, (typename GL::J *)partials, shift, total_buckets);
+                return;
+            }
+        }
         hipLaunchKernelGGL(msm_accumulate_kernel<G>, grid(max_runs), dim3(256), 0, s, (const typename G::A *)aff, sorted,
                            offsets, run_offsets, (typename G::J *)partials, shift, total_buckets);
     }
@@ -1108,6 +1135,12 @@ struct Launch {
     static void endo_subgroup(hipStream_t s, const uint8_t *in, int cin, uint64_t n, int *err) {
         if constexpr (G::J::CfgT::ENDO_KIND != 0) {
             if (!n) return;
+            if constexpr (!std::is_void_v<GL>) {
+                if (!cin && lane_pair_enabled()) {
+                    hipLaunchKernelGGL((endo_subgroup_kernel<GL, 0>), grid(n * 2), dim3(256), 0, s, in, n, err);
+                    return;
+                }
+            }
             if (cin) hipLaunchKernelGGL((endo_subgroup_kernel<G, 1>), grid(n), dim3(256), 0, s, in, n, err);
             else hipLaunchKernelGGL((endo_subgroup_kernel<G, 0>), grid(n), dim3(256), 0, s, in, n, err);
         }

@@ -222,3 +222,24 @@ def test_full_size_round_trip(name, group, log2n, pkg, cref):
     k = 128
     assert w[:k * u] == cref.apply_powers(name, group, v[:k * u], k, start, tau, None, False, False, nthreads=8)
     assert w[-k * u:] == cref.apply_powers(name, group, v[-k * u:], k, start + n - k, tau, None, False, False, nthreads=8)
+
+
+@pytest.mark.parametrize("name,group", [("bls12_377", 1), ("bls12_377", 2), ("bw6", 2), ("mnt4_753", 2)])
+def test_update_passes_points_at_infinity_through(name, group, pkg, cref):
+    """Points at infinity inside a vector (CheckForCorrectness::No lets them through, as the reference's read_batch with
+    Validate::No does) stay at infinity and do not disturb their neighbours — on the lane-pair G2 kernels the infinity
+    flag lives in one lane's bytes and must reach both lanes."""
+    from oracle.pyref import serde
+    from oracle.pyref.curves import CURVES
+    from oracle.pyref.ec import Group
+    c = CURVES[name]
+    G = Group(c, group)
+    rng = random.Random(77)
+    pts = [None if i in (0, 3, 4, 9) else G.mul(G.gen, rng.randrange(1, c.r)) for i in range(10)]
+    data = serde.write_batch(G, pts, False)
+    tau = rng.randrange(c.r)
+    for cout in (True, False):
+        got = pkg.phase1_cli.apply_powers(name, group, data, 10, 5, tau, None, False, cout)
+        assert got == cref.apply_powers(name, group, data, 10, 5, tau, None, False, cout)
+    inf_c = serde.write_point(G, None, True)
+    assert got is not None and pkg.phase1_cli.apply_powers(name, group, data, 10, 5, tau, None, False, True)[:G.comp_size] == inf_c
