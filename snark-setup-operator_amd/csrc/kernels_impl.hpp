@@ -19,6 +19,9 @@
 #ifndef PTAU_G1_MIN_WAVES
 #define PTAU_G1_MIN_WAVES 2
 #endif
+#ifndef PTAU_K1_G1_MIN_WAVES
+#define PTAU_K1_G1_MIN_WAVES 3   // tau-update of a 12-limb G1: measured 26.2 M/s at 3 waves (168 VGPRs, 400 B of spills), 25.1 at 2, 23.7 at 4
+#endif
 #ifndef PTAU_LANE_MIN_WAVES
 #define PTAU_LANE_MIN_WAVES 2
 #endif
@@ -53,6 +56,7 @@ struct GroupTypes {
     // go through out-of-line callees the bound does not reach (single-lane Fq2 / Fq3 callees keep their 512 registers and
     // one wave per SIMD), but the 24-limb prime-field groups' callees fit 248 VGPRs, so bounding the kernel body (276
     // otherwise) is what gets BW6-761 and MNT G1 to two waves.
+    static constexpr int K1_MIN_WAVES = (LPP == 1 && sizeof(F) <= 48) ? PTAU_K1_G1_MIN_WAVES : 0;   // 0: same as MIN_WAVES
     static constexpr int MIN_WAVES = LPP == 2 ? PTAU_LANE_MIN_WAVES : sizeof(F) <= 48 ? PTAU_G1_MIN_WAVES : (PTAU_MIN_WAVES_WIDE > 0 && sizeof(F) > 48 ? PTAU_MIN_WAVES_WIDE : 1);
 };
 
@@ -531,7 +535,7 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
 // VGPR allocation is the maximum over its call graph — the uncompressed instance (the tau-update of a challenge)
 // does not carry it.
 template <class G, int CIN>
-__global__ void __launch_bounds__(256, G::MIN_WAVES)
+__global__ void __launch_bounds__(256, G::K1_MIN_WAVES ? G::K1_MIN_WAVES : G::MIN_WAVES)
 window_scalar_mul_kernel(const uint8_t *__restrict__ in, typename G::J *__restrict__ scratch,
                          typename G::J *__restrict__ wtab, uint64_t n, ScalarSource src, int check_input,
                          int use_glv, int *__restrict__ err) {
