@@ -4,7 +4,7 @@
 // BLS12-377, MNT4-753 (D = 2) and MNT6-753 (D = 3)); NR is a small signed integer so the
 // non-residue product is a short addition chain instead of a field multiplication.
 #pragma once
-#include "fp.hpp"
+#include "fp29.hpp"
 
 namespace ptau {
 
@@ -291,7 +291,7 @@ struct Fp3 {
     // and sqrt(a) = sqrt_Fq(N(a)) / b.   One 753-bit Fq3 exponentiation + one base-field sqrt.
     __host__ __device__ __noinline__ static bool sqrt(const Fp3 &a, Fp3 &out) {
         if (a.is_zero()) { out = zero(); return true; }
-        Fp3 b = frobenius(pow_limbs(a, F::Params::QP1H, F::Params::BITS - 1));
+        Fp3 b = frobenius(pow_limbs(a, F::Params::QP1H_E, F::Params::BITS - 1));
         Fp3 nrm = mul(sqr(b), a);
         if (!nrm.c1.is_zero() || !nrm.c2.is_zero()) return false;   // cannot happen for valid field data
         F s;

@@ -16,6 +16,9 @@ MNT4_B1 = 2879880390345638889141003679329940576494037236009993834075257640639388
 MNT6_B1 = 11625908999541321152027340224010374716841167701783584648338908235410859267060079819722747939267925389062611062156601938166010098747920378738927832658133625454260115409075816187555055859490253375704728027944315501122723426879114
 BLS_G2_B1 = 155198655607781456406391640216936120121836107652948796323930557600032281009004493664981332883744016074664192874906
 
+# base fields whose curves use the reduced-radix (2^29) field class
+RADIX29 = {"BlsFq"}
+
 
 # Synthetic order-r generators of the MNT twists (arkworks' constants are not recoverable offline):
 # smallest x = (k, 1[, 0]) on the twist, positive y, times the twist cofactor.
@@ -77,38 +80,54 @@ def glv_lattice(r, lam):
     return v1, v2
 
 
-def limbs(x, n):
-    return ", ".join("0x%08xu" % ((x >> (32 * i)) & 0xFFFFFFFF) for i in range(n))
+_LB = 32   # limb width of the field whose Montgomery constants are being emitted (set by field() / coeffs() / pairing_cfg())
 
 
-def field(name, p, cubic_nr=None, sqrt_tables=False):
-    n = (p.bit_length() + 31) // 32
-    R = 1 << (32 * n)
-    inv = (-pow(p, -1, 1 << 32)) % (1 << 32)
+def limbs(x, n, lb=None):
+    lb = lb or _LB
+    return ", ".join("0x%08xu" % ((x >> (lb * i)) & ((1 << lb) - 1)) for i in range(n))
+
+
+def field(name, p, cubic_nr=None, sqrt_tables=False, lb=32):
+    """Parameter struct of one prime field.  lb = 32: full 32-bit limbs (Fp, fp.hpp).  lb = 29: reduced radix (Fp29,
+    fp29.hpp): ceil(bits/29) limbs of 29 bits, R = 2^(29 N), so that the 2N products of a product-scanning column fit a
+    64-bit accumulator and the multiply-accumulate needs no carry instruction.  Exponents and the *32 arrays stay packed."""
+    global _LB
+    _LB = lb
+    n = (p.bit_length() + lb - 1) // lb
+    n32 = (p.bit_length() + 31) // 32
+    R = 1 << (lb * n)
+    inv = (-pow(p, -1, 1 << lb)) % (1 << lb)
     s = []
     s.append("struct %s {" % name)
+    s.append("  static constexpr int LB = %d;" % lb)
     s.append("  static constexpr int N = %d;" % n)
+    s.append("  static constexpr int N32 = %d;" % n32)
     s.append("  static constexpr int BITS = %d;" % p.bit_length())
     s.append("  static constexpr int BYTES = %d;" % ((p.bit_length() + 7) // 8))
     s.append("  static constexpr uint32_t INV = 0x%08xu;" % inv)
     s.append("  static constexpr uint32_t MOD[%d] = {%s};" % (n, limbs(p, n)))
+    s.append("  static constexpr uint32_t MOD32[%d] = {%s};   // packed" % (n32, limbs(p, n32, 32)))
     s.append("  static constexpr uint32_t R1[%d] = {%s};" % (n, limbs(R % p, n)))
     s.append("  static constexpr uint32_t R2[%d] = {%s};" % (n, limbs(R * R % p, n)))
     s.append("  static constexpr uint32_t HALF[%d] = {%s};  // (p-1)/2" % (n, limbs((p - 1) // 2, n)))
-    s.append("  static constexpr uint32_t PM2[%d] = {%s};   // p-2" % (n, limbs(p - 2, n)))
-    # Tonelli-Shanks data in Fp: p-1 = 2^S * T
+    s.append("  static constexpr uint32_t PM2[%d] = {%s};   // p-2, packed exponent" % (n32, limbs(p - 2, n32, 32)))
     S = ((p - 1) & -(p - 1)).bit_length() - 1
     T = (p - 1) >> S
     z = 2
     while pow(z, (p - 1) // 2, p) != p - 1:
         z += 1
     s.append("  static constexpr int TS_S = %d;" % S)
-    s.append("  static constexpr uint32_t TS_T[%d] = {%s};      // odd part of p-1" % (n, limbs(T, n)))
-    s.append("  static constexpr uint32_t TS_T1H[%d] = {%s};    // (T+1)/2" % (n, limbs((T + 1) // 2, n)))
-    s.append("  static constexpr uint32_t TS_C[%d] = {%s};      // nonresidue^T (Montgomery)" % (n, limbs(pow(z, T, p) * R % p, n)))
-    s.append("  static constexpr uint32_t QP1H[%d] = {%s};      // (p+1)/2" % (n, limbs((p + 1) // 2, n)))
-    s.append("  static constexpr uint32_t TS_TM1H[%d] = {%s};   // (T-1)/2" % (n, limbs((T - 1) // 2, n)))
+    s.append("  static constexpr uint32_t QP1H[%d] = {%s};      // (p+1)/2 = 1/2, canonical limbs" % (n, limbs((p + 1) // 2, n)))
+    s.append("  static constexpr uint32_t QP1H_E[%d] = {%s};    // (p+1)/2, packed exponent" % (n32, limbs((p + 1) // 2, n32, 32)))
+    s.append("  static constexpr uint32_t TS_TM1H[%d] = {%s};   // (T-1)/2, packed exponent" % (n32, limbs((T - 1) // 2, n32, 32)))
     s.append("  static constexpr int TS_TM1H_BITS = %d;" % max(1, ((T - 1) // 2).bit_length()))
+    if lb != 32:
+        # inversion runs on the packed twin struct (same modulus, 32-bit limbs): see Fp29::inverse
+        s.append("  using Twin32 = %s;" % name[:-3])
+        e = 3 * lb * n - 64 * n32
+        fix = pow(2, e, p) if e >= 0 else pow(pow(2, -e, p), -1, p)
+        s.append("  static constexpr uint32_t INV_FIX[%d] = {%s};   // 2^(3*%d*N - 64*N32) mod p" % (n, limbs(fix, n), lb))
     if sqrt_tables:
         # Pohlig-Hellman data for the 2-Sylow part of the square root (fp.hpp sqrt_ex): g = z^T generates the
         # 2^S-torsion; a residue has a^T = (g^2)^d with d < 2^E, E = S-1, found W bits at a time from the bottom.
@@ -123,7 +142,7 @@ def field(name, p, cubic_nr=None, sqrt_tables=False):
         if W:
             h = g * g % p
             zeta = pow(h, 1 << (E - W), p)
-            zl = [pow(zeta, k, p) * R % p & 0xFFFFFFFF for k in range(1 << W)]
+            zl = [pow(zeta, k, p) * R % p & ((1 << lb) - 1) for k in range(1 << W)]
             assert len(set(zl)) == len(zl), "low-limb collision in the sqrt lookup table"
             s.append("  static constexpr uint32_t SQRT_ZLOW[%d] = {%s};" % (1 << W, ", ".join("0x%08xu" % v for v in zl)))
             ginv = pow(g, -1, p)
@@ -156,14 +175,23 @@ def main():
     fields = {}
     for name, p in (("BlsFq", BLS_Q), ("BlsFr", BLS_R), ("Bw6Fq", BW6_Q), ("Mnt4Fq", MNT_A), ("Mnt6Fq", MNT_B)):
         txt, n, R = field(name, p, cubic_nr=11 if name == "Mnt6Fq" else None, sqrt_tables=name.endswith("Fq"))
-        fields[name] = (p, n, R)
+        fields[name] = (p, n, R, 32)
         out.append(txt)
+    # reduced-radix twins for the base fields of the curves listed in RADIX29 (the radix-32 structs stay: they are also the
+    # SCALAR fields of BW6-761 / MNT6 / MNT4, and scalars are consumed as packed 32-bit words)
+    for name, p in (("BlsFq", BLS_Q), ("Bw6Fq", BW6_Q), ("Mnt4Fq", MNT_A), ("Mnt6Fq", MNT_B)):
+        if name in RADIX29:
+            txt, n, R = field(name + "R29", p, cubic_nr=11 if name == "Mnt6Fq" else None, sqrt_tables=True, lb=29)
+            fields[name + "R29"] = (p, n, R, 29)
+            out.append(txt)
+    fq_of = lambda base: base + "R29" if base in RADIX29 else base   # the struct a curve over `base` is generated for
     out.append("using Bw6Fr = BlsFq;")
     out.append("using Mnt4Fr = Mnt6Fq;")
     out.append("using Mnt6Fr = Mnt4Fq;")
 
     def coeffs(cname, fname, deg, a, b, nr, glv=None, endo=None, glv2=None):
-        p, n, R = fields[fname]
+        global _LB
+        p, n, R, _LB = fields[fname]
         s = ["struct %s {" % cname]
         s.append("  static constexpr bool HAS_GLV = %s;" % ("true" if glv else "false"))
         # endomorphism-based subgroup membership test (eprint 2021/1130):
@@ -207,12 +235,12 @@ def main():
                 assert abs(v) < 1 << 192
             assert g1 < 1 << 224 and g2 < 1 << 224
             s.append("  static constexpr uint32_t GLV_BETA[%d] = {%s};" % (n, limbs(beta * R % p, n)))
-            s.append("  static constexpr uint32_t GLV2_A1[6] = {%s};" % limbs(abs(a1), 6))
-            s.append("  static constexpr uint32_t GLV2_A2[6] = {%s};" % limbs(abs(a2), 6))
-            s.append("  static constexpr uint32_t GLV2_B1[6] = {%s};" % limbs(abs(b1), 6))
-            s.append("  static constexpr uint32_t GLV2_B2[6] = {%s};" % limbs(abs(b2), 6))
-            s.append("  static constexpr uint32_t GLV2_G1[7] = {%s};" % limbs(g1, 7))
-            s.append("  static constexpr uint32_t GLV2_G2[7] = {%s};" % limbs(g2, 7))
+            s.append("  static constexpr uint32_t GLV2_A1[6] = {%s};" % limbs(abs(a1), 6, 32))
+            s.append("  static constexpr uint32_t GLV2_A2[6] = {%s};" % limbs(abs(a2), 6, 32))
+            s.append("  static constexpr uint32_t GLV2_B1[6] = {%s};" % limbs(abs(b1), 6, 32))
+            s.append("  static constexpr uint32_t GLV2_B2[6] = {%s};" % limbs(abs(b2), 6, 32))
+            s.append("  static constexpr uint32_t GLV2_G1[7] = {%s};" % limbs(g1, 7, 32))
+            s.append("  static constexpr uint32_t GLV2_G2[7] = {%s};" % limbs(g2, 7, 32))
             s.append("  static constexpr int GLV2_E11 = %d, GLV2_E12 = %d, GLV2_E21 = %d, GLV2_E22 = %d;" % (e11, e12, e21, e22))
         if glv:
             # phi(x, y) = (BETA x, y) = LAMBDA * (x, y) on the prime-order subgroup; k = k1 + k2*LAMBDA with
@@ -220,8 +248,8 @@ def main():
             beta, lam = glv
             assert lam.bit_length() <= 127
             s.append("  static constexpr uint32_t GLV_BETA[%d] = {%s};" % (n, limbs(beta * R % p, n)))
-            s.append("  static constexpr uint32_t GLV_LAMBDA[4] = {%s};" % limbs(lam, 4))
-            s.append("  static constexpr uint32_t GLV_M[5] = {%s};" % limbs((1 << 256) // lam, 5))
+            s.append("  static constexpr uint32_t GLV_LAMBDA[4] = {%s};" % limbs(lam, 4, 32))
+            s.append("  static constexpr uint32_t GLV_M[5] = {%s};" % limbs((1 << 256) // lam, 5, 32))
         s.append("  static constexpr int DEG = %d;" % deg)
         s.append("  static constexpr bool A_IS_ZERO = %s;" % ("true" if not any(a) else "false"))
         # a = A_SMALL * u^A_SHIFT when exactly one coefficient is set and small (doubling uses an addition chain)
@@ -244,7 +272,7 @@ def main():
     bls_beta = pow(g, 2 * (BLS_Q - 1) // 3, BLS_Q)   # the cube root of unity matching lambda = x^2 - 1 (tests check phi(G) = lambda G)
     # lambda^2 = -x^2 mod r is the eigenvalue of beta^2: the G1 membership test compares (beta^2 x, y) with -[x^2]P
     assert (bls_lambda * bls_lambda + bls_x * bls_x) % BLS_R == 0
-    out.append(coeffs("BlsG1Cfg", "BlsFq", 1, (0,), (1,), 0, glv=(bls_beta, bls_lambda),
+    out.append(coeffs("BlsG1Cfg", fq_of("BlsFq"), 1, (0,), (1,), 0, glv=(bls_beta, bls_lambda),
                       endo=(1, bls_x, bls_beta * bls_beta % BLS_Q, 0)))
     # psi(x, y) = (xi^((q-1)/3) conj(x), xi^((q-1)/2) conj(y)), xi = u (D-type twist, b' = b/xi); both constants lie in Fq.
     # Sound because q - x = r (x-1)^2/3 and gcd((x-1)^2/3, #E'(Fq2)/r) = 1 (checked in tests/test_oracle.py).
@@ -258,7 +286,7 @@ def main():
         return r0, r1
     psi_cx, psi_cy = fq2_pow_u((BLS_Q - 1) // 3), fq2_pow_u((BLS_Q - 1) // 2)
     assert psi_cx[1] == 0 and psi_cy[1] == 0
-    out.append(coeffs("BlsG2Cfg", "BlsFq", 2, (0, 0), (0, BLS_G2_B1), -5, endo=(2, bls_x, psi_cx[0], psi_cy[0])))
+    out.append(coeffs("BlsG2Cfg", fq_of("BlsFq"), 2, (0, 0), (0, BLS_G2_B1), -5, endo=(2, bls_x, psi_cx[0], psi_cy[0])))
     # BW6-761: both groups are j = 0 curves over Fq; one eigenvalue lambda (316 bits), the matching cube root of unity
     # per group (checked against the generators: phi(G) = lambda G)
     gq = 2
@@ -271,18 +299,19 @@ def main():
     bw6_lam = pow(hr, 2 * (BLS_Q - 1) // 3, BLS_Q)
     if bw6_lam.bit_length() > 320:
         bw6_lam = bw6_lam * bw6_lam % BLS_Q
-    out.append(coeffs("Bw6G1Cfg", "Bw6Fq", 1, (0,), (BW6_Q - 1,), 0, glv2=(glv_beta_for(BW6_G1_XY, bw6_w, bw6_lam, BW6_Q), bw6_lam, BLS_Q)))
-    out.append(coeffs("Bw6G2Cfg", "Bw6Fq", 1, (0,), (4,), 0, glv2=(glv_beta_for(BW6_G2_XY, bw6_w, bw6_lam, BW6_Q), bw6_lam, BLS_Q)))
-    out.append(coeffs("Mnt4G1Cfg", "Mnt4Fq", 1, (2,), (MNT4_B1,), 0))
-    out.append(coeffs("Mnt4G2Cfg", "Mnt4Fq", 2, (26, 0), (0, MNT4_B1 * 13 % MNT_A), 13))
-    out.append(coeffs("Mnt6G1Cfg", "Mnt6Fq", 1, (11,), (MNT6_B1,), 0))
-    out.append(coeffs("Mnt6G2Cfg", "Mnt6Fq", 3, (0, 0, 11), (MNT6_B1 * 11 % MNT_B, 0, 0), 11))
+    out.append(coeffs("Bw6G1Cfg", fq_of("Bw6Fq"), 1, (0,), (BW6_Q - 1,), 0, glv2=(glv_beta_for(BW6_G1_XY, bw6_w, bw6_lam, BW6_Q), bw6_lam, BLS_Q)))
+    out.append(coeffs("Bw6G2Cfg", fq_of("Bw6Fq"), 1, (0,), (4,), 0, glv2=(glv_beta_for(BW6_G2_XY, bw6_w, bw6_lam, BW6_Q), bw6_lam, BLS_Q)))
+    out.append(coeffs("Mnt4G1Cfg", fq_of("Mnt4Fq"), 1, (2,), (MNT4_B1,), 0))
+    out.append(coeffs("Mnt4G2Cfg", fq_of("Mnt4Fq"), 2, (26, 0), (0, MNT4_B1 * 13 % MNT_A), 13))
+    out.append(coeffs("Mnt6G1Cfg", fq_of("Mnt6Fq"), 1, (11,), (MNT6_B1,), 0))
+    out.append(coeffs("Mnt6G2Cfg", fq_of("Mnt6Fq"), 3, (0, 0, 11), (MNT6_B1 * 11 % MNT_B, 0, 0), 11))
     # ---- pairing tail (host): Fq^k = Fq[w]/(w^k - NU), untwist sign, Frobenius constant, hard exponent
     def cyclo(k, q):
         return {4: q * q + 1, 6: q * q - q + 1, 12: q ** 4 - q * q + 1}[k]
 
     def pairing_cfg(cname, fname, r, k, nu, sign):
-        p, n, R = fields[fname]
+        global _LB
+        p, n, R, _LB = fields[fname]
         assert (p - 1) % k == 0
         gamma1 = pow(nu % p, (p - 1) // k, p)
         hard = cyclo(k, p)
@@ -296,14 +325,14 @@ def main():
         s.append("  static constexpr uint32_t GAMMA1[%d] = {%s};   // NU^((q-1)/K), Montgomery" % (n, limbs(gamma1 * R % p, n)))
         s.append("  static constexpr uint32_t NU_INV[%d] = {%s};   // 1/NU, Montgomery" % (n, limbs(pow(nu % p, -1, p) * R % p, n)))
         s.append("  static constexpr int HARD_BITS = %d;" % hard.bit_length())
-        s.append("  static constexpr uint32_t HARD[%d] = {%s};     // Phi_K(q)/r" % (hl, limbs(hard, hl)))
+        s.append("  static constexpr uint32_t HARD[%d] = {%s};     // Phi_K(q)/r" % (hl, limbs(hard, hl, 32)))
         s.append("};")
         return "\n".join(s)
 
-    out.append(pairing_cfg("BlsPairingCfg", "BlsFq", BLS_R, 12, -5, +1))
-    out.append(pairing_cfg("Bw6PairingCfg", "Bw6Fq", BLS_Q, 6, -4, -1))
-    out.append(pairing_cfg("Mnt4PairingCfg", "Mnt4Fq", MNT_B, 4, 13, -1))
-    out.append(pairing_cfg("Mnt6PairingCfg", "Mnt6Fq", MNT_A, 6, 11, -1))
+    out.append(pairing_cfg("BlsPairingCfg", fq_of("BlsFq"), BLS_R, 12, -5, +1))
+    out.append(pairing_cfg("Bw6PairingCfg", fq_of("Bw6Fq"), BLS_Q, 6, -4, -1))
+    out.append(pairing_cfg("Mnt4PairingCfg", fq_of("Mnt4Fq"), MNT_B, 4, 13, -1))
+    out.append(pairing_cfg("Mnt6PairingCfg", fq_of("Mnt6Fq"), MNT_A, 6, 11, -1))
     # ---- generators, arkworks uncompressed serialisation (x | y + sign flag): Phase1::initialization
     def ser(p, coords_x, coords_y):
         nb = (p.bit_length() + 7) // 8

@@ -39,8 +39,8 @@ constexpr int SCALAR_TABLE_ENTRIES = 64;   // tau^(2^k), k < 64, preceded by the
 // Host+device view of one group's types.
 template <class FqP, class FrP, class Cfg, bool LANE_PAIR = false>
 struct GroupTypes {
-    using Fq = Fp<FqP>;
-    using Fr = Fp<FrP>;
+    using Fq = FieldOf<FqP>;   // Fp (32-bit limbs) or Fp29 (29-bit limbs), as the parameter struct was generated
+    using Fr = Fp<FrP>;        // scalars are consumed as packed 32-bit words
     // LANE_PAIR: an Fq2 element spread over two adjacent lanes (Fp2L, ext.hpp) — two threads per point
     using F = std::conditional_t<Cfg::DEG == 1, Fq,
               std::conditional_t<Cfg::DEG == 2, std::conditional_t<LANE_PAIR, Fp2L<Fq, Cfg::NR>, Fp2<Fq, Cfg::NR>>,
@@ -56,8 +56,9 @@ struct GroupTypes {
     // go through out-of-line callees the bound does not reach (single-lane Fq2 / Fq3 callees keep their 512 registers and
     // one wave per SIMD), but the 24-limb prime-field groups' callees fit 248 VGPRs, so bounding the kernel body (276
     // otherwise) is what gets BW6-761 and MNT G1 to two waves.
-    static constexpr int K1_MIN_WAVES = (LPP == 1 && sizeof(F) <= 48) ? PTAU_K1_G1_MIN_WAVES : 0;   // 0: same as MIN_WAVES
-    static constexpr int MIN_WAVES = LPP == 2 ? PTAU_LANE_MIN_WAVES : sizeof(F) <= 48 ? PTAU_G1_MIN_WAVES : (PTAU_MIN_WAVES_WIDE > 0 && sizeof(F) > 48 ? PTAU_MIN_WAVES_WIDE : 1);
+    static constexpr bool SMALL = F::DEG == 1 && !F::MUL_OUT_OF_LINE;   // a point operation inlines at <= 256 registers
+    static constexpr int K1_MIN_WAVES = (LPP == 1 && SMALL) ? PTAU_K1_G1_MIN_WAVES : 0;   // 0: same as MIN_WAVES
+    static constexpr int MIN_WAVES = LPP == 2 ? PTAU_LANE_MIN_WAVES : SMALL ? PTAU_G1_MIN_WAVES : (PTAU_MIN_WAVES_WIDE > 0 ? PTAU_MIN_WAVES_WIDE : 1);
 };
 
 // table layout: [0] = base coefficient c*tau^start, [1+k] = tau^(2^k); all Montgomery, Fr::N limbs

@@ -17,7 +17,7 @@ namespace ptau {
 
 template <class FqP, class PC>
 struct ExtK {
-    using Fq = Fp<FqP>;
+    using Fq = FieldOf<FqP>;
     static constexpr int K = PC::K;
     std::array<Fq, K> c;
 
@@ -113,7 +113,7 @@ struct ExtK {
 
 template <class FqP, class FrP, class G1Cfg, class G2Cfg, class PC>
 struct TatePairing {
-    using Fq = Fp<FqP>;
+    using Fq = FieldOf<FqP>;
     using E = ExtK<FqP, PC>;
     static constexpr int K = PC::K;
     static constexpr int DEG2 = G2Cfg::DEG;

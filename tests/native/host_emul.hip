@@ -128,7 +128,7 @@ int main(int argc, char **argv) {
     uint64_t n = strtoull(argv[4], 0, 10), start = strtoull(argv[5], 0, 10);
     int cin = atoi(argv[6]), cout = atoi(argv[7]);
     switch (curve) {
-    case 0: DISPATCH(BlsFq, BlsFr, BlsG1Cfg, BlsG2Cfg)
+    case 0: DISPATCH(BlsFqR29, BlsFr, BlsG1Cfg, BlsG2Cfg)
     case 1: DISPATCH(Bw6Fq, Bw6Fr, Bw6G1Cfg, Bw6G2Cfg)
     case 2: DISPATCH(Mnt4Fq, Mnt4Fr, Mnt4G1Cfg, Mnt4G2Cfg)
     case 3: DISPATCH(Mnt6Fq, Mnt6Fr, Mnt6G1Cfg, Mnt6G2Cfg)
