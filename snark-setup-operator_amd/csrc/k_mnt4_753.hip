@@ -2,8 +2,8 @@
 #include "kernels_impl.hpp"
 
 namespace ptau {
-using G1T = GroupTypes<Mnt4Fq, Mnt4Fr, Mnt4G1Cfg>;
-using G2T = GroupTypes<Mnt4Fq, Mnt4Fr, Mnt4G2Cfg>;
+using G1T = GroupTypes<Mnt4FqR29, Mnt4Fr, Mnt4G1Cfg>;
+using G2T = GroupTypes<Mnt4FqR29, Mnt4Fr, Mnt4G2Cfg>;
 // (a lane-pair twin of G2T measured SLOWER here — 138 k vs 217 k updates/s: the 24-limb base products go by reference
 // through memory, so halving the register footprint buys nothing and schoolbook costs 4/3 of Karatsuba)
 

@@ -2,8 +2,8 @@
 #include "kernels_impl.hpp"
 
 namespace ptau {
-using G1T = GroupTypes<Mnt6Fq, Mnt6Fr, Mnt6G1Cfg>;
-using G2T = GroupTypes<Mnt6Fq, Mnt6Fr, Mnt6G2Cfg>;
+using G1T = GroupTypes<Mnt6FqR29, Mnt6Fr, Mnt6G1Cfg>;
+using G2T = GroupTypes<Mnt6FqR29, Mnt6Fr, Mnt6G2Cfg>;
 
 const GroupOps *ops_mnt6_753(int group) {
     static const GroupOps o1 = Launch<G1T>::ops();

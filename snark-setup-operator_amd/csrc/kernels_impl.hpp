@@ -20,7 +20,10 @@
 #define PTAU_G1_MIN_WAVES 2
 #endif
 #ifndef PTAU_K1_G1_MIN_WAVES
-#define PTAU_K1_G1_MIN_WAVES 3   // tau-update of a 12-limb G1: measured 26.2 M/s at 3 waves (168 VGPRs, 400 B of spills), 25.1 at 2, 23.7 at 4
+// tau-update of a 13-limb G1: 0 = as PTAU_G1_MIN_WAVES.  With 29-bit limbs two waves (247 VGPRs, 64 B of spills) run at
+// 31.4 M updates/s and three waves (168 VGPRs, 384 B of spills, 6x the store traffic) at 31.1 M; with 32-bit limbs three
+// waves were 4 % ahead (26.1 vs 25.1 M).
+#define PTAU_K1_G1_MIN_WAVES 0
 #endif
 #ifndef PTAU_LANE_MIN_WAVES
 #define PTAU_LANE_MIN_WAVES 2
