@@ -255,7 +255,7 @@ def main():
         print(json.dumps({
             "metric": "G1 point-updates/sec per chunk (contribute)", "value": value, "unit": "G1 point-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 (29-bit limbs)",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
             "data": "synthetic",
             "config": {"workload": "BLS12-377 phase-1 power 20, chunk_size 2^20: tauG1 vector of one chunk per GPU "
                                    "(2^%d points, uncompressed in -> compressed out, HBM-resident)" % args.log2_points,

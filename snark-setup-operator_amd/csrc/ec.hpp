@@ -51,7 +51,7 @@ struct Jac {
 
     // Point operations on wide fields are single out-of-line copies (code size / compile time);
     // the 12-limb G1 path keeps them inlined so coordinates stay in VGPRs.
-    static constexpr bool OPS_OUT_OF_LINE = !((F::DEG == 1 || F::LANES == 2) && !F::MUL_OUT_OF_LINE);
+    static constexpr bool OPS_OUT_OF_LINE = !F::POINT_OPS_INLINE;
     __host__ __device__ __noinline__ static Jac dbl_out(const Jac &p) { return dbl_inl(p); }
     __host__ __device__ __noinline__ static Jac add_mixed_out(const Jac &p, const Affine<F> &q) { return add_mixed_inl(p, q); }
     __host__ __device__ __noinline__ static Jac add_out(const Jac &p, const Jac &q) { return add_inl(p, q); }

@@ -26,7 +26,8 @@ struct Fp2 {
     PTAU_HD static Fp2 dbl(const Fp2 &a) { return {F::dbl(a.c0), F::dbl(a.c1)}; }
     // Over a 12-limb base the three base products are register-ABI calls (Fp::mul_vec), so the Karatsuba glue is
     // inlined and operands never leave the VGPRs; over 24 limbs the whole product is one by-reference function.
-    static constexpr bool MUL_OUT_OF_LINE = (F::N > 12);
+    static constexpr bool MUL_OUT_OF_LINE = F::MUL_OUT_OF_LINE;
+    static constexpr bool POINT_OPS_INLINE = false;
     __host__ __device__ __noinline__ static Fp2 mul_out(const Fp2 &a, const Fp2 &b) { return mul_inl(a, b); }
     __host__ __device__ __noinline__ static Fp2 sqr_out(const Fp2 &a) { return sqr_inl(a); }
     PTAU_HD static Fp2 mul(const Fp2 &a, const Fp2 &b) {
@@ -139,6 +140,7 @@ struct Fp2L {
     static constexpr int BYTES = 2 * F::BYTES;
     static constexpr int LANES = 2;
     static constexpr bool MUL_OUT_OF_LINE = false;
+    static constexpr bool POINT_OPS_INLINE = F::POINT_OPS_INLINE;
     using Base = F;
     F c;   // a0 on even lanes, a1 on odd lanes
 
@@ -244,6 +246,7 @@ struct Fp3 {
     PTAU_HD static Fp3 neg(const Fp3 &a) { return {F::neg(a.c0), F::neg(a.c1), F::neg(a.c2)}; }
     PTAU_HD static Fp3 dbl(const Fp3 &a) { return {F::dbl(a.c0), F::dbl(a.c1), F::dbl(a.c2)}; }
     static constexpr bool MUL_OUT_OF_LINE = true;
+    static constexpr bool POINT_OPS_INLINE = false;
     __host__ __device__ __noinline__ static Fp3 mul_out(const Fp3 &a, const Fp3 &b) { return mul_inl(a, b); }
     PTAU_HD static Fp3 mul(const Fp3 &a, const Fp3 &b) {
         if constexpr (MUL_OUT_OF_LINE) return mul_out(a, b);

@@ -233,7 +233,15 @@ struct Fp {
         fips_mul(a.l, b.l, r.l);
         return r;
     }
-    static constexpr bool MUL_OUT_OF_LINE = (N > 12);          // by-reference (memory) convention
+// Products of up to this many limbs use the register ABI (vector arguments in VGPRs), wider ones go by reference.
+// 27 (everything in registers: 32 argument VGPRs, the rest of the second operand on the stack) was measured on MI355X:
+// it cuts the point operations' scratch from 1.4 KB to 88 B but their callers then take AGPRs and run one wave per SIMD
+// — BW6-761 3.2 -> 2.9 M updates/s, MNT4 G2 218 k -> 120 k at 2^18; MNT6 +14 % at 2^16.  13 stays.
+#ifndef PTAU_VEC_ABI_MAX_LIMBS
+#define PTAU_VEC_ABI_MAX_LIMBS 13
+#endif
+    static constexpr bool MUL_OUT_OF_LINE = (N > PTAU_VEC_ABI_MAX_LIMBS);          // by-reference (memory) convention
+    static constexpr bool POINT_OPS_INLINE = (N <= 13);   // a Jacobian point operation over this field inlines at <= 256 registers
     typedef uint32_t VecN __attribute__((ext_vector_type(N)));
     __host__ __device__ __noinline__ static VecN mul_vec(VecN a, VecN b) {
         uint32_t x[N], y[N], r[N];

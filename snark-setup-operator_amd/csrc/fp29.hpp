@@ -191,7 +191,8 @@ struct Fp29 {
         return r;
     }
     // one out-of-line copy per field: register ABI (vector arguments in VGPRs) up to 13 limbs, by reference beyond
-    static constexpr bool MUL_OUT_OF_LINE = (N > 13);
+    static constexpr bool MUL_OUT_OF_LINE = (N > PTAU_VEC_ABI_MAX_LIMBS);
+    static constexpr bool POINT_OPS_INLINE = (N <= 13);
     typedef uint32_t VecN __attribute__((ext_vector_type(N)));
     __host__ __device__ __noinline__ static VecN mul_vec(VecN a, VecN b) {
         uint32_t x[N], y[N], r[N];
@@ -215,7 +216,12 @@ struct Fp29 {
     }
     __host__ __device__ __noinline__ static Fp29 mul_out(const Fp29 &a, const Fp29 &b) { return mul_inl(a, b); }
     __host__ __device__ __noinline__ static Fp29 sqr_out(const Fp29 &a) { return sqr_inl(a); }
+    // -DPTAU_INLINE_MUL13 inlines the 13-limb product at every call site: measured +3.5 % on K1 (32.3 vs 31.2 M updates/s)
+    // for a 10-minute compile of the BLS12-377 translation unit and a 2.5x larger code object — off.
     PTAU_HD static Fp29 mul(const Fp29 &a, const Fp29 &b) {
+#ifdef PTAU_INLINE_MUL13
+        if constexpr (!MUL_OUT_OF_LINE) return mul_inl(a, b);
+#endif
         if constexpr (MUL_OUT_OF_LINE) {
             return mul_out(a, b);
         } else {
@@ -230,6 +236,9 @@ struct Fp29 {
         }
     }
     PTAU_HD static Fp29 sqr(const Fp29 &a) {
+#ifdef PTAU_INLINE_MUL13
+        if constexpr (!MUL_OUT_OF_LINE) return sqr_inl(a);
+#endif
         if constexpr (MUL_OUT_OF_LINE) {
             return sqr_out(a);
         } else {

@@ -59,7 +59,7 @@ struct GroupTypes {
     // go through out-of-line callees the bound does not reach (single-lane Fq2 / Fq3 callees keep their 512 registers and
     // one wave per SIMD), but the 24-limb prime-field groups' callees fit 248 VGPRs, so bounding the kernel body (276
     // otherwise) is what gets BW6-761 and MNT G1 to two waves.
-    static constexpr bool SMALL = F::DEG == 1 && !F::MUL_OUT_OF_LINE;   // a point operation inlines at <= 256 registers
+    static constexpr bool SMALL = F::DEG == 1 && F::POINT_OPS_INLINE;   // a point operation inlines at <= 256 registers
     static constexpr int K1_MIN_WAVES = (LPP == 1 && SMALL) ? PTAU_K1_G1_MIN_WAVES : 0;   // 0: same as MIN_WAVES
     static constexpr int MIN_WAVES = LPP == 2 ? PTAU_LANE_MIN_WAVES : SMALL ? PTAU_G1_MIN_WAVES : (PTAU_MIN_WAVES_WIDE > 0 ? PTAU_MIN_WAVES_WIDE : 1);
 };
