@@ -966,7 +966,7 @@ int verify_chunk_impl(const ptau_params *p, const uint8_t *challenge, size_t cha
     const GroupOps *g1 = get_ops(p->curve, 1), *g2 = get_ops(p->curve, 2);
     DeviceCtx *c;
     if ((rc = ensure_ctx(device, c, err))) return rc;
-    std::lock_guard<std::mutex> lk(c->mu);
+    std::unique_lock<std::mutex> lk(c->mu);   // held for the device section only: pairings and digests below run unlocked
     HIP_TRY(hipSetDevice(device));
     c->timing = ptau_timing{};
     (void)check_input;   // DEFAULT_VERIFY_CHECK_INPUT_CORRECTNESS = No: the challenge was produced by this verifier
@@ -997,6 +997,7 @@ int verify_chunk_impl(const ptau_params *p, const uint8_t *challenge, size_t cha
         po += v.n * v.ops->uncomp;
         nc_ready.store((size_t)(po - new_challenge), std::memory_order_release);
     }
+    lk.unlock();   // another lane may use the device while this one finishes its host tail
     if (ratio_check) {
         // check_power_ratios: consecutive elements of every vector differ by the SAME factor tau, i.e.
         // (sum rho_i v_i, sum rho_i v_{i+1}) has the ratio of (tauG2[j], tauG2[j+1]) resp. (tauG1[j], tauG1[j+1]).
