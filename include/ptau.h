@@ -38,7 +38,8 @@ enum { PTAU_MODE_CHUNKED = 0, PTAU_MODE_FULL = 1 };
 enum { PTAU_PROVING_GROTH16 = 0, PTAU_PROVING_MARLIN = 1 };
 /* setup_utils::CheckForCorrectness — src/bin/contribute.rs:38-43,816-819,971-980 */
 enum { PTAU_CHECK_NO = 0, PTAU_CHECK_ONLY_NON_ZERO = 1, PTAU_CHECK_ONLY_IN_GROUP = 2, PTAU_CHECK_FULL = 3 };
-/* setup_utils::SubgroupCheckMode — src/bin/contribute.rs:140-145 */
+/* setup_utils::SubgroupCheckMode — src/bin/contribute.rs:140-145.  AUTO, DIRECT and BATCHED all run the EXACT per-element
+ * membership test (endomorphism test on BLS12-377, [r]P == O elsewhere): same accept/reject set as Direct. */
 enum { PTAU_SUBGROUP_AUTO = 0, PTAU_SUBGROUP_DIRECT = 1, PTAU_SUBGROUP_BATCHED = 2, PTAU_SUBGROUP_NO = 3 };
 /* setup_utils::BatchExpMode — src/bin/contribute.rs:134-139 (all values run the same GPU path) */
 enum { PTAU_BATCH_EXP_AUTO = 0, PTAU_BATCH_EXP_DIRECT = 1, PTAU_BATCH_EXP_BATCH_INVERSION = 2 };

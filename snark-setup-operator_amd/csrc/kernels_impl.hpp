@@ -1,15 +1,21 @@
-// HIP kernels of the chunk tau-update (K1) and point decompression (K2), templated over one
-// group of one curve; each curve's translation unit instantiates them (k_<curve>.hip).
+// HIP kernels of the chunked powers-of-tau hot path, templated over one group of one curve; each curve's translation
+// unit instantiates them (k_<curve>.hip) and capi.hip orchestrates them behind the C ABI (include/ptau.h).
 //
-// Replaces setup-utils' apply_powers / batch_exp / read_batch / write_batch and
-// Phase1::decompress — reference call sites /root/reference/src/bin/contribute.rs:811-823, 968-986.
+// Replaces setup-utils' apply_powers / batch_exp / read_batch / write_batch, Phase1::decompress, check_subgroup and
+// dense_multiexp / power_pairs — reference call sites /root/reference/src/bin/contribute.rs:811-823, 968-986,
+// src/bin/verify_transcript.rs:812-822, src/bin/control.rs:587-591.
 //
-// Pipeline per vector of n points (all device-resident):
-//   scalar_mul_kernel : thread i derives e_i = c * tau^(start+i) from a tau^(2^k) table, reads
-//                       point i (uncompressed, or compressed + sqrt), runs the scalar multiplication
-//                       and stores the Jacobian result to scratch.
-//   normalize_kernel  : Montgomery-trick batched inversion (one inversion per K points), affine
-//                       conversion, arkworks serialisation (sign flag from the canonical y).
+//   K1  window_scalar_mul_kernel : thread i derives e_i = c * tau^(start+i) from a tau^(2^k) table, reads point i, builds
+//                                  its window table 1P..8P in HBM and runs the signed 4-bit window multiplication —
+//                                  GLV (2 half-length scalars, phi) on BLS12-377 G1 and BW6-761, GLS (4 x 64-bit, psi) on
+//                                  BLS12-377 G2 with every Fq2 element spread over a lane pair — Jacobian result to scratch;
+//       normalize_kernel         : Montgomery-trick batched inversion, affine conversion, arkworks serialisation.
+//   K2  decompress_kernel        : compressed -> uncompressed (square root).
+//   K3  endo_subgroup_kernel     : prime-order membership through phi / psi (BLS12-377); other curves: K1 with the group
+//                                  order as scalar + expect_infinity_kernel.
+//   K4  msm_* / reduce_rows      : bucket-method multi-scalar multiplication (plain sum and the shifted sum of power_pairs).
+// The per-thread bodies are host+device so that tests/native/host_emul.hip can run the SAME code on the CPU against the
+// oracle (test infrastructure only: the product has no CPU path).
 #pragma once
 #include <cstdlib>
 #include <type_traits>
