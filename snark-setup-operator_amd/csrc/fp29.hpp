@@ -15,21 +15,11 @@
 
 namespace ptau {
 
-// acc += x * y, 64-bit accumulator, no carry out by construction
-PTAU_HD void mac64_vv(uint64_t &acc, uint32_t x, uint32_t y) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(x), "v"(y) : "vcc");
-#else
-    acc += (uint64_t)x * y;
-#endif
-}
-PTAU_HD void mac64_vs(uint64_t &acc, uint32_t x, uint32_t c) {   // c: compile-time constant (SGPR / literal)
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(x), "s"(c) : "vcc");
-#else
-    acc += (uint64_t)x * c;
-#endif
-}
+// acc += x * y, 64-bit accumulator, no carry out by construction.  Plain C++: the compiler selects v_mad_u64_u32 itself
+// (no carry flag to thread through, unlike the 32-bit form), and — unlike one-instruction asm statements, each of which
+// was followed by a hazard s_nop: 314 per product — schedules the chain freely.
+PTAU_HD void mac64_vv(uint64_t &acc, uint32_t x, uint32_t y) { acc += (uint64_t)x * y; }
+PTAU_HD void mac64_vs(uint64_t &acc, uint32_t x, uint32_t c) { acc += (uint64_t)x * c; }   // c: compile-time constant
 
 template <class P>
 struct Fp29 {
