@@ -11,9 +11,8 @@ constexpr int N = 13, LB = 29;
 constexpr uint32_t MASK = (1u << LB) - 1;
 struct P29 { uint32_t mod[N]; uint32_t inv; };
 
-__device__ __forceinline__ void mac(uint64_t &acc, uint32_t x, uint32_t y) {
-    asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(x), "v"(y) : "vcc");
-}
+// plain C++: the compiler selects v_mad_u64_u32 and schedules the chain (one-instruction asm statements each drew a hazard s_nop)
+__device__ __forceinline__ void mac(uint64_t &acc, uint32_t x, uint32_t y) { acc += (uint64_t)x * y; }
 template <bool SQR>
 __device__ __forceinline__ void mul29(const uint32_t (&a)[N], const uint32_t (&b)[N], const P29 &p, uint32_t (&out)[N]) {
     uint32_t m[N], r[N], d[N];
