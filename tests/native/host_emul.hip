@@ -4,6 +4,8 @@
 //
 // usage: host_emul <op> <curve> <group> <n> <start> <cin> <cout> <tau_hex> <coeff_hex|-> < in > out
 //   op = apply | decompress
+//        field : base-field arithmetic of the group's Fq class.  stdin = n pairs (a, b) of canonical BYTES-long elements;
+//               stdout per pair: a+b | a-b | a*b | a^2 | -a | 1/a (0 for a = 0) | sqrt flag byte + root (0 when none) | sign byte
 //        subgroup : stdin = n points; stdout = n bytes of error bits (0 = in the prime-order subgroup)
 //        msm  : stdin = n points (uncompressed) then n x Fr::N u32 scalar limbs; <start> = window bits c (0 = the
 //               library's own plan), <cout> = 1 adds the shifted sum (needs n + 1 points); stdout = 1 or 2 points
@@ -35,6 +37,33 @@ static int run(const std::string &op, uint64_t n, uint64_t start, int cin, int c
     std::vector<uint8_t> in(n * isz), out;
     if (fread(in.data(), 1, in.size(), stdin) != in.size()) return 2;
     int bad = 0;
+    if (op == "field") {
+        using Fq = typename G::Fq;
+        const int B = Fq::BYTES;
+        in.resize(n * 2 * B);
+        if (fread(in.data() + n * isz, 1, in.size() - n * isz, stdin) != in.size() - n * isz && in.size() > n * isz) return 2;
+        out.assign(n * (8 * B + 2), 0);
+        for (uint64_t i = 0; i < n; i++) {
+            Fq a, b;
+            uint8_t fl = 0;
+            if (!Fq::read_bytes(in.data() + (2 * i) * B, false, &fl, a) || !Fq::read_bytes(in.data() + (2 * i + 1) * B, false, &fl, b)) return 5;
+            uint8_t *o = out.data() + i * (8 * B + 2);
+            Fq::add(a, b).write_bytes(o, 0);
+            Fq::sub(a, b).write_bytes(o + B, 0);
+            Fq::mul(a, b).write_bytes(o + 2 * B, 0);
+            Fq::sqr(a).write_bytes(o + 3 * B, 0);
+            Fq::neg(a).write_bytes(o + 4 * B, 0);
+            Fq::inverse(a).write_bytes(o + 5 * B, 0);
+            Fq r = Fq::zero();
+            const bool ok = Fq::sqrt(a, r);
+            o[6 * B] = ok ? 1 : 0;
+            (ok ? r : Fq::zero()).write_bytes(o + 6 * B + 1, 0);
+            o[7 * B + 1] = (uint8_t)(a.sign_class() + 1);
+            // second serialisation slot keeps the layout fixed-size
+        }
+        fwrite(out.data(), 1, out.size(), stdout);
+        return 0;
+    }
     if (op == "msm") {
         // the per-thread bodies of the bucket MSM (K4), serial on the CPU, same order of launches as capi.hip
         using J = typename G::J;

@@ -206,3 +206,41 @@ def test_endomorphism_scalar_mul_bodies_on_host(name, group, n, cref):
         assert r.returncode == 0 and r.stdout == exp
         r2 = subprocess.run([exe] + args, input=data, capture_output=True, env=dict(os.environ, PTAU_GLV="0"))
         assert r2.returncode == 0 and r2.stdout == exp
+
+
+@pytest.mark.parametrize("name", CURVE_NAMES)
+def test_base_field_arithmetic_on_host(name):
+    """The base-field class each curve's kernels are instantiated with (29-bit limbs for BLS12-377 / MNT, 32-bit for
+    BW6-761), run on the CPU, against Python integers: add, sub, mul, square, neg, inverse, square root, sign class and
+    the byte (de)serialisation — on edge values (0, 1, p-1, p-2, (p±1)/2, limb-boundary patterns) and random ones."""
+    import random
+    exe = os.path.join(ROOT, "tests", "native", "host_emul")
+    if not os.path.exists(exe):
+        pytest.skip("host_emul not built")
+    cv = CURVES[name]
+    p, B = cv.q, cv.fq_bytes
+    rng = random.Random(5)
+    edge = [0, 1, 2, p - 1, p - 2, (p - 1) // 2, (p + 1) // 2, (1 << 29) - 1, 1 << 29, (1 << 32) - 1, 1 << 32,
+            (1 << 58) - 1, (1 << 348) + 1, (1 << (p.bit_length() - 1)) - 1, 1 << (p.bit_length() - 1),
+            int("1fffffff" * 12, 16) % p, int("ffffffff" * 11, 16) % p]
+    vals = [(a, b) for a in edge for b in (0, 1, p - 1, edge[(edge.index(a) * 7 + 3) % len(edge)])]
+    vals += [(rng.randrange(p), rng.randrange(p)) for _ in range(100)]
+    vals += [(a * a % p, rng.randrange(p)) for a, _ in vals[-40:]]          # guaranteed residues
+    data = b"".join(a.to_bytes(B, "little") + b.to_bytes(B, "little") for a, b in vals)
+    # the emulator's generic reader consumes n * uncompressed-size bytes first: G1 uncompressed = 2 * B = one pair
+    r = subprocess.run([exe, "field", str(CURVE_NAMES.index(name)), "1", str(len(vals)), "0", "0", "0", "0", "-"], input=data,
+                       capture_output=True)
+    assert r.returncode == 0, r.returncode
+    rec = 8 * B + 2
+    assert len(r.stdout) == rec * len(vals)
+    half = (p - 1) // 2
+    for i, (a, b) in enumerate(vals):
+        o = r.stdout[i * rec:(i + 1) * rec]
+        g = lambda k: int.from_bytes(o[k * B:(k + 1) * B], "little")
+        assert g(0) == (a + b) % p and g(1) == (a - b) % p and g(2) == a * b % p and g(3) == a * a % p and g(4) == (-a) % p
+        assert g(5) == (pow(a, -1, p) if a else 0)
+        is_res = a == 0 or pow(a, half, p) == 1
+        assert o[6 * B] == (1 if is_res else 0)
+        root = int.from_bytes(o[6 * B + 1:7 * B + 1], "little")
+        assert (root * root % p == a) if is_res else root == 0
+        assert o[7 * B + 1] == (1 if a == 0 else (2 if a > half else 0))
