@@ -354,3 +354,23 @@ def test_contribute_check_input_in_group(name, group, pkg, cref):
     with pytest.raises(pkg.PtauError) as e:
         pkg.phase1_cli.apply_powers(name, group, inf, 2, 0, tau, check_input=pkg.CheckForCorrectness.OnlyNonZero)
     assert e.value.code == -4
+
+
+def test_power_pairs_across_msm_slices(pkg):
+    """More points than one bucket pass takes (MSM_SLICE_POINTS = 2^22) and than one tau-update launch takes (2^20): the
+    geometric vector v_i = s^i G of 2^22 + 5 points still reduces to (A, B) with B = s*A, and a single swapped pair of
+    elements in the LAST slice breaks the relation."""
+    name, n = "bls12_377", (1 << 22) + 5
+    c = CURVES[name]
+    G = Group(c, 1)
+    s = 0x1234567890abcdef1234567890abcdef % c.r
+    gen = serde.write_point(G, G.gen, False) * n
+    v = pkg.phase1_cli.apply_powers(name, 1, gen, n, 0, s, None, False, False)
+    del gen
+    a, b = pkg.phase1_cli.power_pairs(name, 1, v, n)
+    assert pkg.phase1_cli.apply_powers(name, 1, a, 1, 1, s, None, False, False) == b and a != serde.write_point(G, None, False)
+    bad = bytearray(v)
+    o = (n - 3) * 96
+    bad[o:o + 96], bad[o + 96:o + 192] = bad[o + 96:o + 192], bad[o:o + 96]
+    a2, b2 = pkg.phase1_cli.power_pairs(name, 1, bytes(bad), n)
+    assert pkg.phase1_cli.apply_powers(name, 1, a2, 1, 1, s, None, False, False) != b2
