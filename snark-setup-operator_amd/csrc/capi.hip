@@ -353,8 +353,7 @@ int run_msm_bucket_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, i
             std::swap(cur, nxt);
             cols = T;
         }
-        for (int sidx = 0; sidx < nsum; sidx++)
-            ops->msm_horner(c->stream, cur + (size_t)sidx * pl.W * ops->jac_bytes, totals + ((size_t)sidx * nslice + li) * ops->jac_bytes, pl);
+        ops->msm_horner(c->stream, cur, totals + (size_t)li * ops->jac_bytes, pl, nsum, nslice);   // sum s -> totals[s * nslice + li]
     }
     uint8_t *fin = totals + (size_t)nsum * nslice * ops->jac_bytes;
     for (int sidx = 0; sidx < nsum; sidx++)

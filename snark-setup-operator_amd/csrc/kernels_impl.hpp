@@ -837,10 +837,11 @@ PTAU_HD void msm_horner_thread(const typename G::J *win, typename G::J *out, con
     }
     *out = acc;
 }
+// one block per sum (the plain and the shifted sum of power_pairs run side by side): block b reads win + b*W, writes out + b*out_stride
 template <class G>
 __global__ void __launch_bounds__(64)
-msm_horner_kernel(const typename G::J *__restrict__ win, typename G::J *__restrict__ out, MsmPlan pl) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) msm_horner_thread<G>(win, out, pl);
+msm_horner_kernel(const typename G::J *__restrict__ win, typename G::J *__restrict__ out, MsmPlan pl, uint64_t out_stride) {
+    if (threadIdx.x == 0) msm_horner_thread<G>(win + (uint64_t)blockIdx.x * pl.W, out + (uint64_t)blockIdx.x * out_stride, pl);
 }
 
 // y^2 == x^3 + a x + b for uncompressed inputs (compressed reads are on the curve by construction)
@@ -1021,7 +1022,7 @@ struct GroupOps {
     void (*msm_combine)(hipStream_t, const void *partials, const uint32_t *run_offsets, void *buckets, uint64_t total_buckets);
     void (*msm_bucket_reduce)(hipStream_t, const void *buckets, void *parts, MsmPlan pl, uint64_t total);
     void (*reduce_rows)(hipStream_t, const void *in, void *out, uint32_t rows, uint32_t cols, uint32_t T);
-    void (*msm_horner)(hipStream_t, const void *win, void *out, MsmPlan pl);
+    void (*msm_horner)(hipStream_t, const void *win, void *out, MsmPlan pl, int nsum, uint64_t out_stride);
     void (*on_curve)(hipStream_t, const uint8_t *in, uint64_t n, int *err);
     void (*normalize)(hipStream_t, const void *scratch, void *pre, uint8_t *out, int cout, uint64_t n, uint64_t T,
                       int check_nonzero, int *err);
@@ -1129,8 +1130,9 @@ struct Launch {
         hipLaunchKernelGGL(reduce_rows_kernel<G>, grid(total), dim3(256), 0, s, (const typename G::J *)in, (typename G::J *)out,
                            cols, T, total);
     }
-    static void msm_horner(hipStream_t s, const void *win, void *out, MsmPlan pl) {
-        hipLaunchKernelGGL(msm_horner_kernel<G>, dim3(1), dim3(64), 0, s, (const typename G::J *)win, (typename G::J *)out, pl);
+    static void msm_horner(hipStream_t s, const void *win, void *out, MsmPlan pl, int nsum, uint64_t out_stride) {
+        hipLaunchKernelGGL(msm_horner_kernel<G>, dim3(nsum), dim3(64), 0, s, (const typename G::J *)win, (typename G::J *)out, pl,
+                           out_stride);
     }
     static void on_curve(hipStream_t s, const uint8_t *in, uint64_t n, int *err) {
         if (!n) return;
