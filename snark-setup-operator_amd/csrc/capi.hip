@@ -104,6 +104,20 @@ struct DeviceCtx {
     // (~170 ms of latency on MNT4 G2, ~370 ms on MNT6 G2) and runs beside the vectors instead of after them
     hipStream_t side_stream = nullptr;
     uint8_t *s_buf = nullptr;   // [in 1 KB | out 1 KB | order 256 B | err 16 B | scratch 1 J | wtab 8 J]
+    // verify / combine: the D2H copy of vector k is deferred until vector k+1's first kernels are in the queue, so the
+    // ~25 ms a 100-200 MB copy into freshly mapped file pages takes overlap with compute (two output buffers alternate)
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t cev[2] = {};
+    void *d_out_alt = nullptr;
+    size_t out_alt_cap = 0;
+    int out_sel = 0;
+    struct PendingCopy {
+        const void *src = nullptr;
+        uint8_t *dst = nullptr;
+        size_t bytes = 0;
+        std::atomic<size_t> *ready = nullptr;   // progress mark of the streaming new-challenge hash
+        size_t mark = 0;
+    } pending;
     ptau_timing timing = {};
 };
 DeviceCtx g_ctx[MAX_DEVICES];
@@ -128,6 +142,8 @@ int ensure_ctx(int device, DeviceCtx *&c, const Err &err, bool side = false) {
         HIP_TRY(hipMalloc(&c->d_small, 4096));
         HIP_TRY(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
         HIP_TRY(hipMalloc(&c->s_buf, 16384));
+        HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        for (auto &e : c->cev) HIP_TRY(hipEventCreate(&e));
         c->ready = true;
     }
     return PTAU_OK;
@@ -454,13 +470,12 @@ bool cofactor_is_one(int curve, int group) {
 // Prime-order-subgroup membership of n device-resident points (setup-utils check_subgroup, Direct mode):
 // on-curve test for uncompressed encodings, then [r]P == O with the windowed kernel and ONE public scalar.
 // Cofactor-1 groups (MNT G1) need only the on-curve test.  Caller holds the device mutex.
-int run_subgroup_check_dev(DeviceCtx *c, int curve, int group, const GroupOps *ops, const uint8_t *d_in, int cin, uint64_t n,
-                           const Err &err) {
-    if (!n) return PTAU_OK;
+// Enqueue only (no error-word reset, no synchronisation): events ev[0] / ev[1] bracket the membership kernels.
+int enqueue_subgroup_kernels(DeviceCtx *c, int curve, int group, const GroupOps *ops, const uint8_t *d_in, int cin, uint64_t n,
+                             const Err &err) {
     const int isz = cin ? ops->comp : ops->uncomp;
     const uint64_t launch_cap =
         std::max<uint64_t>(256, std::min(MAX_LAUNCH_POINTS, MAX_WINDOW_TABLE_BYTES / (ptau::WINDOW_ENTRIES * ops->jac_bytes)));
-    HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_table, ops->group_order, sizeof(uint32_t) * ops->fr_limbs32, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     if (ops->endo_subgroup && use_endo_subgroup()) {
@@ -480,6 +495,15 @@ int run_subgroup_check_dev(DeviceCtx *c, int curve, int group, const GroupOps *o
         }
     }
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    return PTAU_OK;
+}
+
+int run_subgroup_check_dev(DeviceCtx *c, int curve, int group, const GroupOps *ops, const uint8_t *d_in, int cin, uint64_t n,
+                           const Err &err) {
+    if (!n) return PTAU_OK;
+    HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
+    int rc = enqueue_subgroup_kernels(c, curve, group, ops, d_in, cin, n, err);
+    if (rc) return rc;
     int bits = 0;
     HIP_TRY(hipMemcpyAsync(&bits, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -492,23 +516,48 @@ int run_subgroup_check_dev(DeviceCtx *c, int curve, int group, const GroupOps *o
     return errbits_to_code(bits, err);
 }
 
+// Land the deferred D2H copy of the previous vector (the host blocks here while the kernels just enqueued run).
+int flush_pending_copy(DeviceCtx *c, const Err &err) {
+    DeviceCtx::PendingCopy &pc = c->pending;
+    if (!pc.bytes) return PTAU_OK;
+    float ms = 0;
+    HIP_TRY(hipEventRecord(c->cev[0], c->copy_stream));
+    HIP_TRY(hipMemcpyAsync(pc.dst, pc.src, pc.bytes, hipMemcpyDeviceToHost, c->copy_stream));
+    HIP_TRY(hipEventRecord(c->cev[1], c->copy_stream));
+    HIP_TRY(hipStreamSynchronize(c->copy_stream));
+    HIP_TRY(hipEventElapsedTime(&ms, c->cev[0], c->cev[1]));
+    c->timing.d2h_ms += ms;
+    if (pc.ready) pc.ready->store(pc.mark, std::memory_order_release);
+    pc.bytes = 0;
+    return PTAU_OK;
+}
+
 // One response vector of a chunk: compressed host bytes -> (sqrt) -> non-zero / subgroup checks -> uncompressed
 // host bytes of the next challenge.  Caller holds the device mutex.
 int run_verify_vector(DeviceCtx *c, int curve, int group, const GroupOps *ops, const uint8_t *in, uint8_t *out, uint64_t n,
                       int check_output, int subgroup_check_mode, const uint64_t *ratio_seed, uint64_t index_base,
-                      uint8_t *pair_a, uint8_t *pair_b, const Err &err) {
+                      uint8_t *pair_a, uint8_t *pair_b, std::atomic<size_t> *ready, size_t ready_mark, const Err &err) {
     if (!n) return PTAU_OK;
     int rc;
+    void *&d_out = c->out_sel ? c->d_out_alt : c->d_out;
+    size_t &d_out_cap = c->out_sel ? c->out_alt_cap : c->out_cap;
+    c->out_sel ^= 1;
     if ((rc = grow(c->d_in, c->in_cap, n * ops->comp, err))) return rc;
-    if ((rc = grow(c->d_out, c->out_cap, n * ops->uncomp, err))) return rc;
+    if ((rc = grow(d_out, d_out_cap, n * ops->uncomp, err))) return rc;
     float ms = 0;
     HIP_TRY(hipEventRecord(c->ev[3], c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_in, in, n * ops->comp, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
     HIP_TRY(hipEventRecord(c->ev[4], c->stream));
     const int nonzero = (check_output == PTAU_CHECK_ONLY_NON_ZERO || check_output == PTAU_CHECK_FULL) ? 1 : 0;
-    ops->decompress(c->stream, (const uint8_t *)c->d_in, (uint8_t *)c->d_out, n, nonzero, c->d_err);
+    ops->decompress(c->stream, (const uint8_t *)c->d_in, (uint8_t *)d_out, n, nonzero, c->d_err);
     HIP_TRY(hipEventRecord(c->ev[5], c->stream));
+    const bool want_subgroup = subgroup_check_mode != PTAU_SUBGROUP_NO || check_output == PTAU_CHECK_ONLY_IN_GROUP ||
+                               check_output == PTAU_CHECK_FULL;
+    // the membership kernels are queued behind the decompression at once (one error word collects both), so that the
+    // previous vector's deferred copy below has real work to hide behind
+    if (want_subgroup && (rc = enqueue_subgroup_kernels(c, curve, group, ops, (const uint8_t *)d_out, 0, n, err))) return rc;
+    if ((rc = flush_pending_copy(c, err))) return rc;
     int bits = 0;
     HIP_TRY(hipMemcpyAsync(&bits, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -518,20 +567,22 @@ int run_verify_vector(DeviceCtx *c, int curve, int group, const GroupOps *ops, c
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[4], c->ev[5]));
     c->timing.kernel_ms += ms;
     c->timing.decompress_ms += ms;
+    if (want_subgroup) {
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+        c->timing.kernel_ms += ms;
+        c->timing.subgroup_ms += ms;
+    }
+    c->timing.points += n;
     if ((rc = errbits_to_code(bits, err))) return rc;
-    const bool want_subgroup = subgroup_check_mode != PTAU_SUBGROUP_NO || check_output == PTAU_CHECK_ONLY_IN_GROUP ||
-                               check_output == PTAU_CHECK_FULL;
-    if (want_subgroup && (rc = run_subgroup_check_dev(c, curve, group, ops, (const uint8_t *)c->d_out, 0, n, err))) return rc;
     if (ratio_seed && n >= 2) {   // power_pairs on the vector while it is still resident in HBM
         const ptau::ScalarSource src{ptau::SCALAR_PRF, nullptr, ratio_seed[0], ratio_seed[1], index_base};
-        if ((rc = run_msm_dev(c, ops, (const uint8_t *)c->d_out, 0, n - 1, src, pair_a, pair_b, 0, err))) return rc;
+        if ((rc = run_msm_dev(c, ops, (const uint8_t *)d_out, 0, n - 1, src, pair_a, pair_b, 0, err))) return rc;
     }
-    HIP_TRY(hipEventRecord(c->ev[3], c->stream));
-    HIP_TRY(hipMemcpyAsync(out, c->d_out, n * ops->uncomp, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipEventRecord(c->ev[4], c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
-    c->timing.d2h_ms += ms;
+    c->pending.src = d_out;
+    c->pending.dst = out;
+    c->pending.bytes = n * ops->uncomp;
+    c->pending.ready = ready;
+    c->pending.mark = ready_mark;
     return PTAU_OK;
 }
 
@@ -1033,6 +1084,7 @@ int verify_chunk_impl(const ptau_params *p, const uint8_t *challenge, size_t cha
     std::unique_lock<std::mutex> lk(c->mu);   // held for the device section only: pairings and digests below run unlocked
     HIP_TRY(hipSetDevice(device));
     c->timing = ptau_timing{};
+    c->pending.bytes = 0;
     (void)check_input;   // DEFAULT_VERIFY_CHECK_INPUT_CORRECTNESS = No: the challenge was produced by this verifier
     const uint64_t n1 = sz.g1_chunk_size, n2 = sz.other_chunk_size;
     const uint8_t *pi = response + 64;
@@ -1060,13 +1112,17 @@ int verify_chunk_impl(const ptau_params *p, const uint8_t *challenge, size_t cha
         vec_out[k] = po;
         uint8_t *pa = pairs.data() + (size_t)k * 2 * g2->uncomp, *pb = pa + g2->uncomp;
         if ((rc = run_verify_vector(c, p->curve, v.group, v.ops, pi, po, v.n, check_output, subgroup_check_mode,
-                                    ratio_check ? seed : nullptr, sz.start, pa, pb, err))) {
+                                    ratio_check ? seed : nullptr, sz.start, pa, pb, &nc_ready,
+                                    (size_t)(po + v.n * v.ops->uncomp - new_challenge), err))) {
             hipStreamSynchronize(c->side_stream);   // never leave device work running past the caller's buffers
             return rc;
         }
         pi += v.n * v.ops->comp;
         po += v.n * v.ops->uncomp;
-        nc_ready.store((size_t)(po - new_challenge), std::memory_order_release);
+    }
+    if ((rc = flush_pending_copy(c, err))) {   // the last vector's copy
+        hipStreamSynchronize(c->side_stream);
+        return rc;
     }
     vec_out[4] = po;
     if ((rc = finish_single_side(c, err))) return rc;
@@ -1310,6 +1366,7 @@ int ptau_combine(const ptau_params *full, uint64_t chunk_size, const uint8_t *co
     std::lock_guard<std::mutex> lk(c->mu);
     HIP_TRY(hipSetDevice(device));
     c->timing = ptau_timing{};
+    c->pending.bytes = 0;
     memset(combined, 0, 64);
     // destination vector bases in the full accumulator
     uint8_t *d_tau_g1 = combined + 64;
@@ -1337,12 +1394,12 @@ int ptau_combine(const ptau_params *full, uint64_t chunk_size, const uint8_t *co
             const uint64_t stored = j == 4 ? 1 : v[j].n;   // every chunk stores beta_g2; only chunk 0's is kept
             if (v[j].n &&
                 (rc = run_verify_vector(c, full->curve, v[j].group, v[j].ops, pi, v[j].dst, v[j].n, PTAU_CHECK_NO,
-                                        PTAU_SUBGROUP_NO, nullptr, 0, nullptr, nullptr, err)))
+                                        PTAU_SUBGROUP_NO, nullptr, 0, nullptr, nullptr, nullptr, 0, err)))
                 return rc;
             pi += stored * v[j].ops->comp;
         }
     }
-    return PTAU_OK;
+    return flush_pending_copy(c, err);   // the last vector's deferred copy
 }
 
 int ptau_transform_ratios(const ptau_params *full, const uint8_t *combined, size_t combined_len, int check_input, int device,
