@@ -169,6 +169,7 @@ int errbits_to_code(int bits, const Err &err) {
 
 int run_subgroup_check_dev(DeviceCtx *c, int curve, int group, const GroupOps *ops, const uint8_t *d_in, int cin, uint64_t n,
                            const Err &err);
+int flush_pending_copy(DeviceCtx *c, const Err &err);
 
 // One vector on device-resident buffers; caller holds the device mutex and has set the device.
 // check_input (setup_utils::CheckForCorrectness): bit 0 = non-zero, bit 1 = in the prime-order subgroup (and on the curve)
@@ -208,6 +209,7 @@ int run_apply_powers_dev(DeviceCtx *c, int curve, int group, const GroupOps *ops
         const uint64_t T = (m + grp - 1) / grp;
         ops->normalize(c->stream, c->scratch, c->pre, d_out + off * osz, cout, m, T, 0, c->d_err);
         HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+        if ((rc = flush_pending_copy(c, err))) return rc;   // the previous vector's deferred D2H lands behind these kernels
         int bits = 0;
         HIP_TRY(hipMemcpyAsync(&bits, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -224,13 +226,19 @@ int run_apply_powers_dev(DeviceCtx *c, int curve, int group, const GroupOps *ops
     return PTAU_OK;
 }
 
+// defer_copy: leave the D2H of the result pending (it lands while the NEXT vector's kernels run — flush_pending_copy);
+// the caller flushes after its last vector.
 int run_apply_powers_host(DeviceCtx *c, int curve, int group, const GroupOps *ops, const uint8_t *in, int cin, uint8_t *out, int cout, uint64_t n,
-                          uint64_t start, const uint64_t *tau, const uint64_t *coeff, int check_input, const Err &err) {
+                          uint64_t start, const uint64_t *tau, const uint64_t *coeff, int check_input, const Err &err,
+                          bool defer_copy = false) {
     const size_t isz = cin ? ops->comp : ops->uncomp, osz = cout ? ops->comp : ops->uncomp;
     if (!n) return PTAU_OK;
     int rc;
+    void *&d_out = c->out_sel ? c->d_out_alt : c->d_out;
+    size_t &d_out_cap = c->out_sel ? c->out_alt_cap : c->out_cap;
+    c->out_sel ^= 1;
     if ((rc = grow(c->d_in, c->in_cap, n * isz, err))) return rc;
-    if ((rc = grow(c->d_out, c->out_cap, n * osz, err))) return rc;
+    if ((rc = grow(d_out, d_out_cap, n * osz, err))) return rc;
     float ms = 0;
     HIP_TRY(hipEventRecord(c->ev[3], c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_in, in, n * isz, hipMemcpyHostToDevice, c->stream));
@@ -238,16 +246,15 @@ int run_apply_powers_host(DeviceCtx *c, int curve, int group, const GroupOps *op
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
     c->timing.h2d_ms += ms;
-    if ((rc = run_apply_powers_dev(c, curve, group, ops, (const uint8_t *)c->d_in, cin, (uint8_t *)c->d_out, cout, n, start, tau, coeff,
+    if ((rc = run_apply_powers_dev(c, curve, group, ops, (const uint8_t *)c->d_in, cin, (uint8_t *)d_out, cout, n, start, tau, coeff,
                                    check_input, err)))
         return rc;
-    HIP_TRY(hipEventRecord(c->ev[3], c->stream));
-    HIP_TRY(hipMemcpyAsync(out, c->d_out, n * osz, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipEventRecord(c->ev[4], c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
-    c->timing.d2h_ms += ms;
-    return PTAU_OK;
+    c->pending.src = d_out;
+    c->pending.dst = out;
+    c->pending.bytes = n * osz;
+    c->pending.ready = nullptr;
+    c->pending.mark = 0;
+    return defer_copy ? PTAU_OK : flush_pending_copy(c, err);
 }
 
 // Exclusive prefix sums over m bucket counts: offsets[0..m] (entries; offsets[m] = total), cursor[j] = offsets[j]
@@ -841,6 +848,7 @@ int ptau_apply_powers_dev(int curve, int group, const void *d_in, int compressed
     std::lock_guard<std::mutex> lk(c->mu);
     HIP_TRY(hipSetDevice(device));
     c->timing = ptau_timing{};
+    c->pending.bytes = 0;   // a copy left pending by a call that failed must never land
     return run_apply_powers_dev(c, curve, group, ops, (const uint8_t *)d_in, compressed_in, (uint8_t *)d_out, compressed_out, n, start, tau,
                                 coeff, check_input, err);
 }
@@ -858,6 +866,7 @@ int ptau_apply_powers(int curve, int group, const uint8_t *in, int compressed_in
     std::lock_guard<std::mutex> lk(c->mu);
     HIP_TRY(hipSetDevice(device));
     c->timing = ptau_timing{};
+    c->pending.bytes = 0;   // a copy left pending by a call that failed must never land
     return run_apply_powers_host(c, curve, group, ops, in, compressed_in, out, compressed_out, n, start, tau, coeff, check_input, err);
 }
 
@@ -882,6 +891,7 @@ int ptau_phase1_computation(const ptau_params *p, const uint8_t *in, size_t in_l
     std::lock_guard<std::mutex> lk(c->mu);
     HIP_TRY(hipSetDevice(device));
     c->timing = ptau_timing{};
+    c->pending.bytes = 0;   // a copy left pending by a call that failed must never land
     const uint64_t n1 = sz.g1_chunk_size, n2 = sz.other_chunk_size, s = sz.start;
     const uint8_t *pi = in + 64;
     uint8_t *po = out + 64;
@@ -891,6 +901,8 @@ int ptau_phase1_computation(const ptau_params *p, const uint8_t *in, size_t in_l
     DeviceCtx *sc;
     if ((rc = ensure_ctx(device, sc, err, /*side=*/true))) return rc;
     sc->timing = ptau_timing{};
+    c->pending.bytes = 0;
+    sc->pending.bytes = 0;
     char side_msg[256] = {0};
     const uint8_t *pi_b = in + sz.accumulator_size - g2->uncomp;
     uint8_t *po_b = out + sz.contribution_size - sz.public_key_size - g2->comp;
@@ -903,14 +915,15 @@ int ptau_phase1_computation(const ptau_params *p, const uint8_t *in, size_t in_l
         std::future<int> &f;
         ~SideJoin() { if (f.valid()) f.wait(); }
     } side_join{side};
-    if ((rc = run_apply_powers_host(c, p->curve, 1, g1, pi, 0, po, 1, n1, s, tau, nullptr, check_input, err))) return rc;
+    if ((rc = run_apply_powers_host(c, p->curve, 1, g1, pi, 0, po, 1, n1, s, tau, nullptr, check_input, err, /*defer_copy=*/true))) return rc;
     pi += n1 * g1->uncomp; po += n1 * g1->comp;
-    if ((rc = run_apply_powers_host(c, p->curve, 2, g2, pi, 0, po, 1, n2, s, tau, nullptr, check_input, err))) return rc;
+    if ((rc = run_apply_powers_host(c, p->curve, 2, g2, pi, 0, po, 1, n2, s, tau, nullptr, check_input, err, /*defer_copy=*/true))) return rc;
     pi += n2 * g2->uncomp; po += n2 * g2->comp;
-    if ((rc = run_apply_powers_host(c, p->curve, 1, g1, pi, 0, po, 1, n2, s, tau, alpha, check_input, err))) return rc;
+    if ((rc = run_apply_powers_host(c, p->curve, 1, g1, pi, 0, po, 1, n2, s, tau, alpha, check_input, err, /*defer_copy=*/true))) return rc;
     pi += n2 * g1->uncomp; po += n2 * g1->comp;
-    if ((rc = run_apply_powers_host(c, p->curve, 1, g1, pi, 0, po, 1, n2, s, tau, beta, check_input, err))) return rc;
+    if ((rc = run_apply_powers_host(c, p->curve, 1, g1, pi, 0, po, 1, n2, s, tau, beta, check_input, err, /*defer_copy=*/true))) return rc;
     pi += n2 * g1->uncomp; po += n2 * g1->comp;
+    if ((rc = flush_pending_copy(c, err))) return rc;   // the last vector's deferred copy
     rc = side.get();
     c->timing.points += 1;
     if (rc) return err.fail(rc, "%s", side_msg);
@@ -968,6 +981,7 @@ int ptau_decompress(int curve, int group, const uint8_t *in, uint8_t *out, uint6
     std::lock_guard<std::mutex> lk(c->mu);
     HIP_TRY(hipSetDevice(device));
     c->timing = ptau_timing{};
+    c->pending.bytes = 0;   // a copy left pending by a call that failed must never land
     if (!n) return PTAU_OK;
     if ((rc = grow(c->d_in, c->in_cap, n * ops->comp, err))) return rc;
     if ((rc = grow(c->d_out, c->out_cap, n * ops->uncomp, err))) return rc;
@@ -1000,6 +1014,7 @@ int ptau_subgroup_check(int curve, int group, const uint8_t *in, int compressed_
     std::lock_guard<std::mutex> lk(c->mu);
     HIP_TRY(hipSetDevice(device));
     c->timing = ptau_timing{};
+    c->pending.bytes = 0;   // a copy left pending by a call that failed must never land
     if (!n) return PTAU_OK;
     const size_t isz = compressed_in ? ops->comp : ops->uncomp;
     if ((rc = grow(c->d_in, c->in_cap, n * isz, err))) return rc;
@@ -1084,7 +1099,7 @@ int verify_chunk_impl(const ptau_params *p, const uint8_t *challenge, size_t cha
     std::unique_lock<std::mutex> lk(c->mu);   // held for the device section only: pairings and digests below run unlocked
     HIP_TRY(hipSetDevice(device));
     c->timing = ptau_timing{};
-    c->pending.bytes = 0;
+    c->pending.bytes = 0;   // a copy left pending by a call that failed must never land
     (void)check_input;   // DEFAULT_VERIFY_CHECK_INPUT_CORRECTNESS = No: the challenge was produced by this verifier
     const uint64_t n1 = sz.g1_chunk_size, n2 = sz.other_chunk_size;
     const uint8_t *pi = response + 64;
@@ -1229,6 +1244,7 @@ int ptau_msm(int curve, int group, const uint8_t *in, int compressed_in, uint64_
     std::lock_guard<std::mutex> lk(c->mu);
     HIP_TRY(hipSetDevice(device));
     c->timing = ptau_timing{};
+    c->pending.bytes = 0;   // a copy left pending by a call that failed must never land
     const size_t isz = compressed_in ? ops->comp : ops->uncomp;
     const int nl64 = (ops->fr_limbs32 + 1) / 2;
     // scalars travel as 32-bit limbs; Fr of BLS12-377 has 8 of them, the 753-bit fields 24
@@ -1269,6 +1285,7 @@ int ptau_power_pairs(int curve, int group, const uint8_t *in, int compressed_in,
     std::lock_guard<std::mutex> lk(c->mu);
     HIP_TRY(hipSetDevice(device));
     c->timing = ptau_timing{};
+    c->pending.bytes = 0;   // a copy left pending by a call that failed must never land
     const size_t isz = compressed_in ? ops->comp : ops->uncomp;
     if ((rc = grow(c->d_in, c->in_cap, n * isz, err))) return rc;
     HIP_TRY(hipMemcpyAsync(c->d_in, in, n * isz, hipMemcpyHostToDevice, c->stream));
@@ -1366,7 +1383,7 @@ int ptau_combine(const ptau_params *full, uint64_t chunk_size, const uint8_t *co
     std::lock_guard<std::mutex> lk(c->mu);
     HIP_TRY(hipSetDevice(device));
     c->timing = ptau_timing{};
-    c->pending.bytes = 0;
+    c->pending.bytes = 0;   // a copy left pending by a call that failed must never land
     memset(combined, 0, 64);
     // destination vector bases in the full accumulator
     uint8_t *d_tau_g1 = combined + 64;
