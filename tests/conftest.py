@@ -11,6 +11,16 @@ if ROOT not in sys.path:
 
 CURVE_NAMES = ["bls12_377", "bw6", "mnt4_753", "mnt6_753"]
 
+# torch first, libptau_hip.so second — the order bench.py uses.  torch bundles its own HIP runtime; when the library's
+# runtime came up first in a process, a later torch.cuda.is_available() was observed to report False on the GPU box
+# (tests/test_gpu_parity.py::test_native_library_loaded run after the verify tests).  Querying torch here fixes the order
+# for every test selection; on the CPU-only container it is simply False.
+try:
+    import torch
+    torch.cuda.is_available()
+except Exception:   # torch is plumbing for the tests, never a requirement of the product
+    pass
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
