@@ -89,8 +89,10 @@ def whole_chunk_extras(pkg, log2n, dev):
     import tempfile
     n = 1 << log2n
     prm = pkg.Phase1Parameters.new_chunk("bls12_377", 0, 0, n, 0, log2n, n)
-    k0 = [det_scalar("bench/k0/%d" % i) for i in range(3)]
-    k1 = [det_scalar("bench/k1/%d" % i) for i in range(3)]
+    seed0, seed1 = b"bench seed 0".ljust(64, b"."), b"bench seed 1".ljust(64, b".")
+    # the coordinator hands a contributor a challenge that came out of a verifier's subgroup checks: the operator-side
+    # integration asserts that and gets the endomorphism path; plain Auto is exact on any curve point
+    verified = int(pkg.BatchExpMode.Auto) | pkg.phase1_cli.INPUT_IN_SUBGROUP
     base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
     d = tempfile.mkdtemp(prefix="ptau_bench_", dir=base)
     f = lambda name: os.path.join(d, name)
@@ -99,9 +101,8 @@ def whole_chunk_extras(pkg, log2n, dev):
                                                                   prm.contribution_size, base or "the default tmp dir")}
     try:
         pkg.new_challenge(f("c0"), f("c0.hash"), prm)
-        pk = bytes(prm.public_key_size)
-        pkg.contribute(f("c0"), f("c0.hash2"), f("r0"), f("r0.hash"), pkg.CheckForCorrectness.No, pkg.BatchExpMode.Auto, prm,
-                       pkg.PrivateKey(*k0, pk), device=dev)
+        pkg.phase1_cli.contribute_seeded(f("c0"), f("c0.hash2"), f("r0"), f("r0.hash"), pkg.CheckForCorrectness.No, pkg.BatchExpMode.Auto,
+                                         prm, seed0, device=dev)
         t0 = time.perf_counter()
         pkg.transform_pok_and_correctness(f("c0"), f("v.c.hash"), pkg.CheckForCorrectness.No, f("r0"), f("v.r.hash"),
                                           pkg.CheckForCorrectness.OnlyNonZero, f("c1"), f("c1.hash"), pkg.SubgroupCheckMode.Auto,
@@ -109,9 +110,10 @@ def whole_chunk_extras(pkg, log2n, dev):
         dt = time.perf_counter() - t0
         tm = pkg.phase1_cli.last_timing(dev)
         out["verify_chunk"] = {"seconds": dt, "chunks_verified_per_s": 1.0 / dt, "elements_per_s": (4 * n + 1) / dt,
-                               "includes": "3 BLAKE2b digests (one host thread per file, overlapped with the device), sqrt "
-                                           "decompression, non-zero + subgroup check of every element, power_pairs of 4 vectors, "
-                                           "4 pairing checks, new challenge written, PCIe both ways",
+                               "includes": "3 BLAKE2b digests (one host thread per file, overlapped with the device), compute_g2_s + 3 proofs "
+                                           "of knowledge + 5 chunk-0 before/after checks, sqrt decompression, non-zero + subgroup check of "
+                                           "every element, power_pairs of 4 vectors, 4 power-ratio pairing checks, new challenge written, "
+                                           "PCIe both ways",
                                "device_ms": tm["kernel_ms"], "decompress_ms": tm["decompress_ms"], "subgroup_ms": tm["subgroup_ms"],
                                "msm_ms": tm["msm_ms"], "h2d_ms": tm["h2d_ms"], "d2h_ms": tm["d2h_ms"]}
         os.remove(f("c1"))
@@ -121,15 +123,18 @@ def whole_chunk_extras(pkg, log2n, dev):
                                           False, prm, device=dev)
         dt2 = time.perf_counter() - t0
         out["verify_chunk_skip_ratio_check"] = {"seconds": dt2, "chunks_verified_per_s": 1.0 / dt2}
-        t0 = time.perf_counter()
-        pkg.contribute(f("c1"), f("c1.hash2"), f("r1"), f("r1.hash"), pkg.CheckForCorrectness.No, pkg.BatchExpMode.Auto, prm,
-                       pkg.PrivateKey(*k1, pk), device=dev)
-        dt3 = time.perf_counter() - t0
-        tm = pkg.phase1_cli.last_timing(dev)
-        out["contribute_chunk"] = {"seconds": dt3, "chunks_per_s": 1.0 / dt3, "g1_equiv_updates_per_s": (4 * n + 1) / dt3,
-                                   "includes": "phase1_cli::contribute on files: BLAKE2b(challenge) overlapped, 5 vectors updated "
-                                               "(PCIe both ways), public key + BLAKE2b(response) + msync",
-                                   "device_ms": tm["kernel_ms"], "h2d_ms": tm["h2d_ms"], "d2h_ms": tm["d2h_ms"]}
+        for tag, mode, what in (("contribute_chunk", verified, "Auto | INPUT_IN_SUBGROUP (challenge produced by the verification above: endomorphism path)"),
+                                ("contribute_chunk_exact", pkg.BatchExpMode.Auto, "Auto, CheckForCorrectness::No (exact on any curve point: plain windows)")):
+            if os.path.exists(f("r1")):
+                os.remove(f("r1"))
+            t0 = time.perf_counter()
+            pkg.phase1_cli.contribute_seeded(f("c1"), f("c1.hash2"), f("r1"), f("r1.hash"), pkg.CheckForCorrectness.No, mode, prm, seed1, device=dev)
+            dt3 = time.perf_counter() - t0
+            tm = pkg.phase1_cli.last_timing(dev)
+            out[tag] = {"seconds": dt3, "chunks_per_s": 1.0 / dt3, "g1_equiv_updates_per_s": (4 * n + 1) / dt3, "batch_exp_mode": what,
+                        "includes": "phase1_cli::contribute on files from a seed: key generation, BLAKE2b(challenge) overlapped, 5 vectors "
+                                    "updated (PCIe both ways), public key + BLAKE2b(response) + msync",
+                        "device_ms": tm["kernel_ms"], "h2d_ms": tm["h2d_ms"], "d2h_ms": tm["d2h_ms"]}
         assert open(f("c1"), "rb").read(64) == open(f("v.r.hash"), "rb").read()   # new challenge extends the response it verified
         # several in-process lanes on ONE GPU (the operator's --max-in-process-lane, contribute.rs:120-121,467-492): the
         # library serialises only the device section of a call, so one lane's BLAKE2b overlaps another lane's kernels
@@ -140,8 +145,8 @@ def whole_chunk_extras(pkg, log2n, dev):
                                                   pkg.CheckForCorrectness.OnlyNonZero, f("L%d.c1" % k), f("L%d.c1.hash" % k),
                                                   pkg.SubgroupCheckMode.Auto, True, prm, device=dev)
             def lane_contribute(k):
-                pkg.contribute(f("c1"), f("L%d.h" % k), f("L%d.r1" % k), f("L%d.r1.hash" % k), pkg.CheckForCorrectness.No,
-                               pkg.BatchExpMode.Auto, prm, pkg.PrivateKey(*k1, pk), device=dev)
+                pkg.phase1_cli.contribute_seeded(f("c1"), f("L%d.h" % k), f("L%d.r1" % k), f("L%d.r1.hash" % k), pkg.CheckForCorrectness.No,
+                                                 verified, prm, seed1, device=dev)
             for name, fn, outs in (("verify", lane_verify, ("L%d.c1",)), ("contribute", lane_contribute, ("L%d.r1",))):
                 th = [threading.Thread(target=fn, args=(k,)) for k in range(lanes)]
                 t0 = time.perf_counter()
@@ -160,8 +165,8 @@ def whole_chunk_extras(pkg, log2n, dev):
         prm1 = pkg.Phase1Parameters.new_chunk("bls12_377", 0, 1, n, 0, log2n, n)
         full = pkg.Phase1Parameters.new_full("bls12_377", 0, log2n, n)
         pkg.new_challenge(f("d0"), f("d0.hash"), prm1)
-        pkg.contribute(f("d0"), f("d0.hash2"), f("s0"), f("s0.hash"), pkg.CheckForCorrectness.No, pkg.BatchExpMode.Auto, prm1,
-                       pkg.PrivateKey(*k0, bytes(prm1.public_key_size)), device=dev)
+        pkg.phase1_cli.contribute_seeded(f("d0"), f("d0.hash2"), f("s0"), f("s0.hash"), pkg.CheckForCorrectness.No, pkg.BatchExpMode.Auto, prm1,
+                                         seed0, device=dev)
         responses = [open(f("r0"), "rb").read(), open(f("s0"), "rb").read()]
         t0 = time.perf_counter()
         combined = pkg.combine(responses, n, full, device=dev)
@@ -216,9 +221,11 @@ def main():
     nl = L.ptau_fr_limbs(0)
     eb = ctypes.create_string_buffer(256)
 
-    def run(d_in, cin, d_out, cout, count, start, tau):
+    ENDO = int(pkg.BatchExpMode.Auto) | pkg.phase1_cli.INPUT_IN_SUBGROUP
+
+    def run(d_in, cin, d_out, cout, count, start, tau, mode=0):
         rc = L.ptau_apply_powers_dev(0, 1, ctypes.c_void_p(d_in.data_ptr()), cin, ctypes.c_void_p(d_out.data_ptr()), cout,
-                                     count, start, pkg._lib.limbs(tau, nl), None, 0, dev, eb, len(eb))
+                                     count, start, pkg._lib.limbs(tau, nl), None, 0, mode, dev, eb, len(eb))
         if rc:
             raise RuntimeError("ptau_apply_powers_dev rc=%d: %s" % (rc, eb.value.decode()))
 
@@ -230,7 +237,7 @@ def main():
     d_gen = torch.frombuffer(bytearray(gen * n), dtype=torch.uint8).cuda()
     d_chal = torch.empty(n * 96, dtype=torch.uint8, device="cuda")
     d_resp = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
-    run(d_gen, 0, d_chal, 0, n, start, s)
+    run(d_gen, 0, d_chal, 0, n, start, s, ENDO)
     del d_gen
 
     def barrier():
@@ -251,6 +258,17 @@ def main():
         norm_ms += tm["normalize_ms"]
     barrier()
     dt = time.perf_counter() - t0
+    # the same step on the endomorphism path (GLV; membership asserted by the caller — what an operator that trusts its
+    # coordinator's verifier runs): reported next to `value`, never as `value`
+    run(d_chal, 0, d_resp, 1, n, start, tau, ENDO)
+    endo_ms = 0.0
+    te = time.perf_counter()
+    for _ in range(args.steps):
+        run(d_chal, 0, d_resp, 1, n, start, tau, ENDO)
+        endo_ms += pkg.phase1_cli.last_timing(dev)["scalar_mul_ms"]
+    torch.cuda.synchronize()
+    dte = time.perf_counter() - te
+    run(d_chal, 0, d_resp, 1, n, start, tau)      # d_resp again holds the exact path's output (parity sample below)
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -289,6 +307,10 @@ def main():
                          "normalize_kernel_ms": norm_ms / args.steps,
                          "note": "integer-ALU-bound by construction (~0.6 M 32x32->64 MACs per update vs 144 B; 58 % of the measured v_mad_u64_u32 issue peak): see DESIGN.md"},
             "cpu_baseline": base,
+            "value_path": "BatchExpMode::Auto with CheckForCorrectness::No (the operator's contribute default): plain signed-window "
+                          "multiplication, exact for ANY curve point",
+            "endomorphism_path": {"value": n * args.steps / dte, "unit": "G1 point-updates/s (this rank)", "kernel_ms": endo_ms / args.steps,
+                                  "batch_exp_mode": "Auto | PTAU_BATCH_EXP_INPUT_IN_SUBGROUP (GLV; same bytes on subgroup points)"},
             "extras": extras,
         }))
     if dist is not None:

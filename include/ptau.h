@@ -41,8 +41,17 @@ enum { PTAU_CHECK_NO = 0, PTAU_CHECK_ONLY_NON_ZERO = 1, PTAU_CHECK_ONLY_IN_GROUP
 /* setup_utils::SubgroupCheckMode — src/bin/contribute.rs:140-145.  AUTO, DIRECT and BATCHED all run the EXACT per-element
  * membership test (endomorphism test on BLS12-377, [r]P == O elsewhere): same accept/reject set as Direct. */
 enum { PTAU_SUBGROUP_AUTO = 0, PTAU_SUBGROUP_DIRECT = 1, PTAU_SUBGROUP_BATCHED = 2, PTAU_SUBGROUP_NO = 3 };
-/* setup_utils::BatchExpMode — src/bin/contribute.rs:134-139 (all values run the same GPU path) */
-enum { PTAU_BATCH_EXP_AUTO = 0, PTAU_BATCH_EXP_DIRECT = 1, PTAU_BATCH_EXP_BATCH_INVERSION = 2 };
+/* setup_utils::BatchExpMode — src/bin/contribute.rs:134-139.  arkworks' batch_exp returns [k]P for ANY curve point, so:
+ *   DIRECT                 : plain signed-window multiplication, exact on the whole curve;
+ *   AUTO / BATCH_INVERSION : the same, EXCEPT when prime-order-subgroup membership of every input element was established
+ *                            in the same call (check_input >= PTAU_CHECK_ONLY_IN_GROUP): then the endomorphism-accelerated
+ *                            multiplication runs (GLV on BLS12-377 G1 / BW6-761, GLS on BLS12-377 G2) — equal to [k]P on the
+ *                            subgroup, ~1.4x faster;
+ *   | PTAU_BATCH_EXP_INPUT_IN_SUBGROUP : the CALLER asserts membership (the challenge came out of a verifier that ran the
+ *                            subgroup checks, which is what the coordinator hands a contributor): the endomorphism path runs
+ *                            without a membership pass.  On an element outside the subgroup the result would differ from
+ *                            the reference's — never set it for data of unknown origin. */
+enum { PTAU_BATCH_EXP_AUTO = 0, PTAU_BATCH_EXP_DIRECT = 1, PTAU_BATCH_EXP_BATCH_INVERSION = 2, PTAU_BATCH_EXP_INPUT_IN_SUBGROUP = 0x100 };
 
 enum {
     PTAU_OK = 0,
@@ -106,13 +115,13 @@ void ptau_blake2b512(const uint8_t *data, size_t len, uint8_t out[64]);
  * `in`/`out` are HOST buffers of n serialized points. coeff may be NULL. */
 int ptau_apply_powers(int curve, int group, const uint8_t *in, int compressed_in, uint8_t *out,
                       int compressed_out, uint64_t n, uint64_t start, const uint64_t *tau,
-                      const uint64_t *coeff, int check_input, int device, char *err, size_t err_len);
+                      const uint64_t *coeff, int check_input, int batch_exp_mode, int device, char *err, size_t err_len);
 
 /* Same, on DEVICE-resident buffers (hipMalloc / torch CUDA tensors): the kernel-only path
  * bench.py times.  Runs on the library's stream for `device` and synchronises before returning. */
 int ptau_apply_powers_dev(int curve, int group, const void *d_in, int compressed_in, void *d_out,
                           int compressed_out, uint64_t n, uint64_t start, const uint64_t *tau,
-                          const uint64_t *coeff, int check_input, int device, char *err, size_t err_len);
+                          const uint64_t *coeff, int check_input, int batch_exp_mode, int device, char *err, size_t err_len);
 
 /* Phase1::computation — inside phase1_cli::contribute (src/bin/contribute.rs:811-823):
  * `in` = whole challenge (accumulator_size, uncompressed), `out` = whole response buffer
@@ -120,10 +129,10 @@ int ptau_apply_powers_dev(int curve, int group, const void *d_in, int compressed
  * hashing, key generation and the public-key write. */
 int ptau_phase1_computation(const ptau_params *p, const uint8_t *in, size_t in_len, uint8_t *out,
                             size_t out_len, const uint64_t *tau, const uint64_t *alpha,
-                            const uint64_t *beta, int check_input, int device, char *err, size_t err_len);
+                            const uint64_t *beta, int check_input, int batch_exp_mode, int device, char *err, size_t err_len);
 
-/* phase1_cli::contribute with the key pair as INPUT (key generation stays on the Rust host,
- * SURVEY §8 a5) — src/bin/contribute.rs:811-823.  Reads `challenge_path` (must be exactly
+/* phase1_cli::contribute with the key pair as INPUT (the Rust host ran Phase1::key_generation itself; see
+ * ptau_contribute_file_seeded for the reference's own seed-driven form) — src/bin/contribute.rs:811-823.  Reads `challenge_path` (must be exactly
  * accumulator_size), writes challenge_hash_path (64 raw bytes), creates response_path
  * (create_new semantics) = hash(challenge) | updated elements | public_key, writes
  * response_hash_path. */
@@ -144,29 +153,40 @@ int ptau_decompress(int curve, int group, const uint8_t *in, uint8_t *out, uint6
 int ptau_subgroup_check(int curve, int group, const uint8_t *in, int compressed_in, uint64_t n, int device,
                         char *err, size_t err_len);
 
-/* Phase1::verification (element part) + Phase1::decompress — inside
- * phase1_cli::transform_pok_and_correctness (src/bin/contribute.rs:968-986):
+/* Phase1::verification + Phase1::decompress on buffers — inside phase1_cli::transform_pok_and_correctness
+ * (src/bin/contribute.rs:968-986):
  *   - response[0..64) must equal BLAKE2b(challenge)             -> PTAU_E_HASH_CHAIN
+ *   - check_input (CheckForCorrectness of the CHALLENGE elements, --force-correctness-checks, contribute.rs:133,971-974):
+ *     non-zero / on the curve and in the prime-order subgroup      -> PTAU_E_POINT_AT_INFINITY / _NOT_IN_SUBGROUP / _POINT
  *   - every response element: canonical, on the curve, non-zero per check_output, in the prime-order
  *     subgroup unless subgroup_check_mode == PTAU_SUBGROUP_NO      -> PTAU_E_POINT / _AT_INFINITY / _NOT_IN_SUBGROUP
+ *   - verify_pok != 0: the three proofs of knowledge of the PublicKey at the tail of `response` and, for chunk 0 / Full
+ *     mode, the before/after checks (ptau_verify_pok).  g2_s = the three compute_g2_s points (tau, alpha, beta;
+ *     UNCOMPRESSED) or NULL: derived by the library from BLAKE2b(challenge) and the public key (ptau_compute_g2_s).
+ *     verify_pok == 0 leaves them out (element checks only: tests, and callers that run ptau_verify_pok themselves).
  *   - ratio_check (contribute.rs:146-147,954,984): check_power_ratios of every vector — power_pairs on the GPU,
- *     check_same_ratio on the host — against (tauG2[j], tauG2[j+1]) / (tauG1[j], tauG1[j+1]) of this chunk;
- *     a chunk without tauG2 elements (start >= 2^power) needs tau_g2_check = two UNCOMPRESSED G2 points
- *     (tauG2[0], tauG2[1]) of the same contribution, else NULL          -> PTAU_E_INVALID_RATIO
- *   - new_challenge = BLAKE2b(response) | decompressed elements (accumulator_size bytes).
- * The proof-of-knowledge checks on the public key are ptau_verify_pok. */
+ *     check_same_ratio on the host — against (tauG2[j], tauG2[j+1]) / (tauG1[j], tauG1[j+1]) of this chunk.  A chunk
+ *     without tauG2 elements (start >= 2^power) has no G2 pair of ratio tau in its own files: its tauG1 power ratios are
+ *     checked when the caller supplies tau_g2_check = two UNCOMPRESSED G2 points (tauG2[0], tauG2[1]) of the same
+ *     contribution, and are otherwise left to ptau_transform_ratios on the combined accumulator (src/bin/control.rs:587-591)
+ *     — never an error for an honest response                          -> PTAU_E_INVALID_RATIO
+ *   - new_challenge = BLAKE2b(response) | decompressed elements (accumulator_size bytes). */
 int ptau_verify_chunk(const ptau_params *p, const uint8_t *challenge, size_t challenge_len, const uint8_t *response,
                       size_t response_len, uint8_t *new_challenge, size_t new_challenge_len, int check_input,
-                      int check_output, int subgroup_check_mode, int ratio_check, const uint8_t *tau_g2_check,
-                      int device, char *err, size_t err_len);
+                      int check_output, int subgroup_check_mode, int ratio_check, int verify_pok, const uint8_t *g2_s,
+                      const uint8_t *tau_g2_check, int device, char *err, size_t err_len);
 
-/* phase1_cli::transform_pok_and_correctness, file level (src/bin/contribute.rs:968-986): writes the three
- * 64-byte `.hash` side files and creates new_challenge_path (create_new semantics). */
+/* phase1_cli::transform_pok_and_correctness, file level (src/bin/contribute.rs:968-986), the reference's eleven
+ * arguments in the reference's order: hash chain, CheckForCorrectness of the challenge, PROOFS OF KNOWLEDGE and chunk-0
+ * before/after checks (always), element checks, ratio checks, decompression; writes the three 64-byte `.hash` side files
+ * and creates new_challenge_path (create_new semantics).  g2_s: NULL (derived by the library, as the reference does) or
+ * the three compute_g2_s points computed by the Rust host (uncompressed), which removes the one step whose bit-exactness
+ * with arkworks cannot be pinned offline (ptau_compute_g2_s). */
 int ptau_transform_pok_and_correctness_file(const ptau_params *p, const char *challenge_path,
                                             const char *challenge_hash_path, int check_input, const char *response_path,
                                             const char *response_hash_path, int check_output,
                                             const char *new_challenge_path, const char *new_challenge_hash_path,
-                                            int subgroup_check_mode, int ratio_check, const uint8_t *tau_g2_check,
+                                            int subgroup_check_mode, int ratio_check, const uint8_t *g2_s,
                                             int device, char *err, size_t err_len);
 
 /* setup_utils::dense_multiexp — sum_i scalars[i] * in[i] -> one serialized point (host buffers; scalars are
@@ -191,11 +211,18 @@ int ptau_check_same_ratio(int curve, const uint8_t *g1_a, const uint8_t *g1_b, c
 
 /* Phase1::initialization via phase1_cli::new_challenge (src/bin/new_setup.rs:105-109, verify_transcript.rs:322-326):
  * blank BLAKE2b hash, then every element = the group generator, uncompressed (host only, no GPU needed).
- * NOTE: the MNT4/MNT6 G2 generators are synthetic order-r points (arkworks' constants are not recoverable
- * offline — DESIGN.md §2). */
+ * BLS12-377 and BW6-761 use the built-in ark-bls12-377 / ark-bw6-761 generators.  MNT4-753 / MNT6-753 return
+ * PTAU_E_UNSUPPORTED: their arkworks G2 generator constants are not recoverable offline and an accumulator
+ * built on any other point would not be the reference's initial challenge — use the _with_generators form. */
 int ptau_new_challenge(const ptau_params *p, uint8_t *out, size_t out_len, char *err, size_t err_len);
 int ptau_new_challenge_file(const ptau_params *p, const char *challenge_path, const char *challenge_hash_path,
                             char *err, size_t err_len);
+/* The same with the generators supplied by the caller (uncompressed bytes of G1Affine::generator() and
+ * G2Affine::generator()): bit-exact with the reference on every curve by construction. */
+int ptau_new_challenge_with_generators(const ptau_params *p, const uint8_t *g1_generator, const uint8_t *g2_generator,
+                                       uint8_t *out, size_t out_len, char *err, size_t err_len);
+/* Built-in generator (uncompressed); PTAU_E_UNSUPPORTED for the G2 of MNT4-753 / MNT6-753. */
+int ptau_generator(int curve, int group, uint8_t *out, size_t out_len, char *err, size_t err_len);
 
 /* Phase1::aggregation via phase1_cli::combine (src/bin/control.rs:564-568, verify_transcript.rs:603-607):
  * n_chunks compressed chunk responses -> one Full-mode UNCOMPRESSED accumulator (64 zero bytes | tauG1 |
@@ -213,10 +240,45 @@ int ptau_transform_ratios(const ptau_params *full, const uint8_t *combined, size
 /* Phase1::verification steps (1)-(2) (inside transform_pok_and_correctness, src/bin/contribute.rs:968-986):
  * the three proofs of knowledge in the PublicKey at the tail of `response`, and for chunk 0 / Full mode the
  * before/after checks (tauG1[1], alphaG1[0], betaG1[0], tauG2[1], betaG2 moved by exactly the public key).
- * g2_s = the three compute_g2_s points (tau, alpha, beta), UNCOMPRESSED, computed by the host: hash_to_g2
- * depends on arkworks' ChaCha-based G2 sampling and stays with key generation on the Rust side. */
+ * g2_s = the three compute_g2_s points (tau, alpha, beta), UNCOMPRESSED, or NULL (derived: ptau_compute_g2_s). */
 int ptau_verify_pok(const ptau_params *p, const uint8_t *challenge, size_t challenge_len, const uint8_t *response,
                     size_t response_len, const uint8_t *g2_s, char *err, size_t err_len);
+
+/* ---- keys (host CPU) ------------------------------------------------------------------------------
+ * setup_utils::derive_rng_from_seed (src/bin/contribute.rs:783-789) = ChaCha20Rng::from_seed(seed[0..32)) of rand_chacha
+ * 0.3.1 (Cargo.lock:2927-2929): the RFC 7539 block function with a 64-bit block counter from 0, stream 0, output consumed
+ * as little-endian 32-bit words in order.  ptau_chacha20_rng_words exposes that word stream (words [offset, offset+n)),
+ * checked against the published ChaCha20 vectors. */
+int ptau_chacha20_rng_words(const uint8_t seed[32], uint64_t word_offset, uint32_t *out, size_t n_words);
+
+/* Phase1::key_generation(rng, digest) with rng = derive_rng_from_seed(seed) (src/bin/contribute.rs:783-789, 811-823):
+ * tau, alpha, beta <- Fr::rand; for x in (tau, alpha, beta), personalization 0, 1, 2: g1_s <- G1::rand, g1_s_x = x g1_s,
+ * g2_s = compute_g2_s(digest, g1_s, g1_s_x, personalization), g2_s_x = x g2_s.  Outputs the scalars as canonical
+ * little-endian limbs (ptau_fr_limbs each) and the PublicKey, uncompressed: tau_g1 (s, s_x), alpha_g1, beta_g1, then
+ * tau_g2, alpha_g2, beta_g2 (public_key_size bytes).  `digest` = BLAKE2b(challenge), 64 bytes.
+ * PARITY UNPINNED: the sampling order and rejection rules restate ark-ff / ark-ec 0.4.2 and rand 0.8 from memory (DESIGN.md
+ * §2); keys are valid whatever the sampling, but equal the reference's only if that recollection is exact. */
+int ptau_key_generation(int curve, const uint8_t *seed, size_t seed_len, const uint8_t digest[64], uint64_t *tau,
+                        uint64_t *alpha, uint64_t *beta, uint8_t *public_key, size_t public_key_len, char *err, size_t err_len);
+
+/* The PrivateKey half alone (the draws that precede anything bound to the digest): lets a contribution start on the
+ * GPU while BLAKE2b(challenge) is still being computed. */
+int ptau_private_key_from_seed(int curve, const uint8_t *seed, size_t seed_len, uint64_t *tau, uint64_t *alpha, uint64_t *beta,
+                               char *err, size_t err_len);
+
+/* setup_utils::compute_g2_s for the three key components of a serialized PublicKey (inside Phase1::verification and
+ * key_generation): g2_s[x] = hash_to_g2(BLAKE2b(personalization x | digest | g1_s | g1_s_x)) — ChaCha20Rng seeded by the
+ * first 32 bytes of that hash, G2Affine::from_random_bytes until a point is found, cofactor cleared.
+ * out = 3 UNCOMPRESSED G2 points.  Same parity caveat as ptau_key_generation. */
+int ptau_compute_g2_s(int curve, const uint8_t digest[64], const uint8_t *public_key, size_t public_key_len, uint8_t *g2_s_out,
+                      char *err, size_t err_len);
+
+/* phase1_cli::contribute in the reference's own form (src/bin/contribute.rs:783-789, 811-823): the key pair comes from
+ * `seed` through derive_rng_from_seed + Phase1::key_generation (the private key is drawn first and the device starts at
+ * once; the public key, which is bound to BLAKE2b(challenge), is made while the GPU works). */
+int ptau_contribute_file_seeded(const ptau_params *p, const char *challenge_path, const char *challenge_hash_path,
+                                const char *response_path, const char *response_hash_path, const uint8_t *seed, size_t seed_len,
+                                int check_input, int batch_exp_mode, int device, char *err, size_t err_len);
 
 /* Timings of the most recent compute call on `device`. */
 int ptau_last_timing(int device, ptau_timing *out);

@@ -20,7 +20,8 @@ DECLARED_SYMBOLS = [
     "ptau_fr_limbs", "ptau_blake2b512", "ptau_apply_powers", "ptau_apply_powers_dev", "ptau_phase1_computation",
     "ptau_contribute_file", "ptau_decompress", "ptau_last_timing", "ptau_subgroup_check", "ptau_verify_chunk",
     "ptau_transform_pok_and_correctness_file", "ptau_msm", "ptau_power_pairs", "ptau_check_same_ratio", "ptau_new_challenge", "ptau_new_challenge_file",
-    "ptau_combine", "ptau_transform_ratios", "ptau_verify_pok",
+    "ptau_combine", "ptau_transform_ratios", "ptau_verify_pok", "ptau_new_challenge_with_generators", "ptau_generator",
+    "ptau_chacha20_rng_words", "ptau_key_generation", "ptau_private_key_from_seed", "ptau_compute_g2_s", "ptau_contribute_file_seeded",
 ]
 
 
@@ -68,9 +69,9 @@ def load_library():
     L.ptau_fr_limbs.argtypes = [i]
     L.ptau_blake2b512.argtypes = [u8p, sz, u8p]
     L.ptau_blake2b512.restype = None
-    L.ptau_apply_powers.argtypes = [i, i, u8p, i, u8p, i, u64, u64, u64p, u64p, i, i, cp, sz]
-    L.ptau_apply_powers_dev.argtypes = [i, i, vp, i, vp, i, u64, u64, u64p, u64p, i, i, cp, sz]
-    L.ptau_phase1_computation.argtypes = [ctypes.POINTER(ptau_params), u8p, sz, u8p, sz, u64p, u64p, u64p, i, i, cp, sz]
+    L.ptau_apply_powers.argtypes = [i, i, u8p, i, u8p, i, u64, u64, u64p, u64p, i, i, i, cp, sz]
+    L.ptau_apply_powers_dev.argtypes = [i, i, vp, i, vp, i, u64, u64, u64p, u64p, i, i, i, cp, sz]
+    L.ptau_phase1_computation.argtypes = [ctypes.POINTER(ptau_params), u8p, sz, u8p, sz, u64p, u64p, u64p, i, i, i, cp, sz]
     L.ptau_contribute_file.argtypes = [ctypes.POINTER(ptau_params), cp, cp, cp, cp, u64p, u64p, u64p, u8p, sz, i, i, i, cp, sz]
     L.ptau_decompress.argtypes = [i, i, u8p, u8p, u64, i, i, cp, sz]
     L.ptau_last_timing.argtypes = [i, ctypes.POINTER(ptau_timing)]
@@ -83,8 +84,15 @@ def load_library():
     L.ptau_transform_ratios.argtypes = [ctypes.POINTER(ptau_params), u8p, sz, i, i, cp, sz]
     L.ptau_verify_pok.argtypes = [ctypes.POINTER(ptau_params), u8p, sz, u8p, sz, u8p, cp, sz]
     L.ptau_subgroup_check.argtypes = [i, i, u8p, i, u64, i, cp, sz]
-    L.ptau_verify_chunk.argtypes = [ctypes.POINTER(ptau_params), u8p, sz, u8p, sz, u8p, sz, i, i, i, i, u8p, i, cp, sz]
+    L.ptau_verify_chunk.argtypes = [ctypes.POINTER(ptau_params), u8p, sz, u8p, sz, u8p, sz, i, i, i, i, i, u8p, u8p, i, cp, sz]
     L.ptau_transform_pok_and_correctness_file.argtypes = [ctypes.POINTER(ptau_params), cp, cp, i, cp, cp, i, cp, cp, i, i, u8p, i, cp, sz]
+    L.ptau_new_challenge_with_generators.argtypes = [ctypes.POINTER(ptau_params), u8p, u8p, u8p, sz, cp, sz]
+    L.ptau_generator.argtypes = [i, i, u8p, sz, cp, sz]
+    L.ptau_chacha20_rng_words.argtypes = [u8p, u64, ctypes.POINTER(ctypes.c_uint32), sz]
+    L.ptau_key_generation.argtypes = [i, u8p, sz, u8p, u64p, u64p, u64p, u8p, sz, cp, sz]
+    L.ptau_private_key_from_seed.argtypes = [i, u8p, sz, u64p, u64p, u64p, cp, sz]
+    L.ptau_compute_g2_s.argtypes = [i, u8p, u8p, sz, u8p, cp, sz]
+    L.ptau_contribute_file_seeded.argtypes = [ctypes.POINTER(ptau_params), cp, cp, cp, cp, u8p, sz, i, i, i, cp, sz]
     _lib = L
     return L
 

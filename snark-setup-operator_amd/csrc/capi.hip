@@ -75,15 +75,18 @@ bool use_window_kernel() {
     return v;
 }
 
-// The GLV path (BLS12-377 G1) assumes its inputs lie in the prime-order subgroup, which holds for every
-// element of a verified challenge.  PTAU_GLV=0 selects the plain windowed multiplication, exact for ANY curve
-// point (BatchExpMode::Direct semantics); the subgroup check itself never uses GLV.
-int use_glv() {
-    static const int v = [] {
-        const char *e = getenv("PTAU_GLV");
-        return (e && strcmp(e, "0") == 0) ? 0 : 1;
-    }();
-    return v;
+// setup_utils::BatchExpMode at the boundary (include/ptau.h).  The endomorphism-accelerated multiplications (GLV on
+// BLS12-377 G1 / BW6-761, GLS on BLS12-377 G2) equal [k]P only on the prime-order subgroup, where phi / psi act as
+// [lambda] / [x]; arkworks' batch_exp computes [k]P for ANY curve point.  So they run only when membership was
+// established in the same call (check_input >= OnlyInGroup runs the subgroup kernels first) or the caller asserts it
+// (PTAU_BATCH_EXP_INPUT_IN_SUBGROUP: the challenge came out of a verifier that ran the subgroup checks); every other
+// combination takes the plain signed-window multiplication, exact on the whole curve.  Returns < 0 on a bad mode.
+int endo_allowed(int check_input, int batch_exp_mode) {
+    const int mode = batch_exp_mode & ~PTAU_BATCH_EXP_INPUT_IN_SUBGROUP;
+    if (mode != PTAU_BATCH_EXP_AUTO && mode != PTAU_BATCH_EXP_DIRECT && mode != PTAU_BATCH_EXP_BATCH_INVERSION) return -1;
+    if (mode == PTAU_BATCH_EXP_DIRECT) return 0;
+    if (batch_exp_mode & PTAU_BATCH_EXP_INPUT_IN_SUBGROUP) return 1;
+    return (check_input & 2) ? 1 : 0;
 }
 
 struct DeviceCtx {
@@ -126,6 +129,12 @@ DeviceCtx g_ctx[MAX_DEVICES];
 // while the main context's mutex is held.
 DeviceCtx g_side_ctx[MAX_DEVICES];
 
+// Lazy per-device initialisation.  Several in-process lanes (threads) may make their FIRST call at the same time
+// (INTEGRATION.md §4): the creation of streams / events / buffers runs under one process-wide mutex, into locals that
+// are committed only when every step succeeded, so a cold multi-thread start neither races nor leaks a half-built
+// context (a failed step destroys what it had created and the next call starts over).
+std::mutex g_init_mu;
+
 int ensure_ctx(int device, DeviceCtx *&c, const Err &err, bool side = false) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
@@ -134,18 +143,34 @@ int ensure_ctx(int device, DeviceCtx *&c, const Err &err, bool side = false) {
         return err.fail(PTAU_E_DEVICE, "device ordinal %d out of range (%d devices)", device, n);
     c = side ? &g_side_ctx[device] : &g_ctx[device];
     HIP_TRY(hipSetDevice(device));
-    if (!c->ready) {
-        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
-        HIP_TRY(hipMalloc(&c->d_table, sizeof(uint32_t) * (1 + ptau::SCALAR_TABLE_ENTRIES) * 24));
-        HIP_TRY(hipMalloc(&c->d_err, sizeof(int)));
-        HIP_TRY(hipMalloc(&c->d_small, 4096));
-        HIP_TRY(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
-        HIP_TRY(hipMalloc(&c->s_buf, 16384));
-        HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-        for (auto &e : c->cev) HIP_TRY(hipEventCreate(&e));
-        c->ready = true;
+    std::lock_guard<std::mutex> init_lk(g_init_mu);
+    if (c->ready) return PTAU_OK;
+    hipStream_t st[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t evs[8] = {};
+    void *bufs[4] = {nullptr, nullptr, nullptr, nullptr};
+    const size_t buf_sz[4] = {sizeof(uint32_t) * (1 + ptau::SCALAR_TABLE_ENTRIES) * 24, 256, 4096, 16384};
+    hipError_t e = hipSuccess;
+    const char *what = "";
+    for (int i = 0; i < 3 && e == hipSuccess; i++) { e = hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking); what = "hipStreamCreateWithFlags"; }
+    for (int i = 0; i < 8 && e == hipSuccess; i++) { e = hipEventCreate(&evs[i]); what = "hipEventCreate"; }
+    for (int i = 0; i < 4 && e == hipSuccess; i++) { e = hipMalloc(&bufs[i], buf_sz[i]); what = "hipMalloc"; }
+    if (e != hipSuccess) {
+        for (auto s : st) if (s) (void)hipStreamDestroy(s);
+        for (auto v : evs) if (v) (void)hipEventDestroy(v);
+        for (auto b : bufs) if (b) (void)hipFree(b);
+        return err.fail(PTAU_E_DEVICE, "device context initialisation: %s failed: %s", what, hipGetErrorString(e));
     }
+    c->stream = st[0];
+    c->side_stream = st[1];
+    c->copy_stream = st[2];
+    for (int i = 0; i < 6; i++) c->ev[i] = evs[i];
+    c->cev[0] = evs[6];
+    c->cev[1] = evs[7];
+    c->d_table = (uint32_t *)bufs[0];
+    c->d_err = (int *)bufs[1];
+    c->d_small = bufs[2];
+    c->s_buf = (uint8_t *)bufs[3];
+    c->ready = true;
     return PTAU_OK;
 }
 
@@ -177,7 +202,7 @@ int flush_pending_copy(DeviceCtx *c, const Err &err);
 // (GLV / GLS) paths exact: they assume subgroup elements, as every element of a verified challenge is.
 int run_apply_powers_dev(DeviceCtx *c, int curve, int group, const GroupOps *ops, const uint8_t *d_in, int cin, uint8_t *d_out, int cout,
                          uint64_t n, uint64_t start, const uint64_t *tau, const uint64_t *coeff, int check_input,
-                         const Err &err) {
+                         int use_endo, const Err &err) {
     const int isz = cin ? ops->comp : ops->uncomp, osz = cout ? ops->comp : ops->uncomp;
     std::vector<uint32_t> table((1 + ptau::SCALAR_TABLE_ENTRIES) * ops->fr_limbs32);
     if (check_input & 2) {
@@ -200,7 +225,7 @@ int run_apply_powers_dev(DeviceCtx *c, int curve, int group, const GroupOps *ops
         HIP_TRY(hipEventRecord(c->ev[0], c->stream));
         if (windowed)
             ops->window_scalar_mul(c->stream, d_in + off * isz, cin, c->scratch, c->wtab, m,
-                                   ptau::ScalarSource{ptau::SCALAR_TAU_TABLE, c->d_table, 0, 0, 0}, check_input, use_glv(), c->d_err);
+                                   ptau::ScalarSource{ptau::SCALAR_TAU_TABLE, c->d_table, 0, 0, 0}, check_input, use_endo, c->d_err);
         else
             ops->scalar_mul(c->stream, d_in + off * isz, cin, c->scratch, m, c->d_table, check_input, c->d_err);
         HIP_TRY(hipEventRecord(c->ev[1], c->stream));
@@ -229,7 +254,7 @@ int run_apply_powers_dev(DeviceCtx *c, int curve, int group, const GroupOps *ops
 // defer_copy: leave the D2H of the result pending (it lands while the NEXT vector's kernels run — flush_pending_copy);
 // the caller flushes after its last vector.
 int run_apply_powers_host(DeviceCtx *c, int curve, int group, const GroupOps *ops, const uint8_t *in, int cin, uint8_t *out, int cout, uint64_t n,
-                          uint64_t start, const uint64_t *tau, const uint64_t *coeff, int check_input, const Err &err,
+                          uint64_t start, const uint64_t *tau, const uint64_t *coeff, int check_input, int use_endo, const Err &err,
                           bool defer_copy = false) {
     const size_t isz = cin ? ops->comp : ops->uncomp, osz = cout ? ops->comp : ops->uncomp;
     if (!n) return PTAU_OK;
@@ -247,7 +272,7 @@ int run_apply_powers_host(DeviceCtx *c, int curve, int group, const GroupOps *op
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
     c->timing.h2d_ms += ms;
     if ((rc = run_apply_powers_dev(c, curve, group, ops, (const uint8_t *)c->d_in, cin, (uint8_t *)d_out, cout, n, start, tau, coeff,
-                                   check_input, err)))
+                                   check_input, use_endo, err)))
         return rc;
     c->pending.src = d_out;
     c->pending.dst = out;
@@ -422,7 +447,7 @@ int run_msm_naive_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, in
         ptau::ScalarSource s2 = src;
         if (s2.mode == ptau::SCALAR_ARRAY) s2.ptr += off * ops->fr_limbs32;
         s2.index_base += off;
-        ops->window_scalar_mul(c->stream, d_in + off * isz, cin, S, c->wtab, m, s2, 0, use_glv(), c->d_err);
+        ops->window_scalar_mul(c->stream, d_in + off * isz, cin, S, c->wtab, m, s2, 0, /*use_endo=*/0, c->d_err);
         // tree: m -> min(m,4096)·.. -> 64 -> 1
         const uint64_t t1 = std::min<uint64_t>(4096, (m + 15) / 16);
         ops->reduce_sum(c->stream, S, level, m, t1);
@@ -837,11 +862,13 @@ int ptau_last_timing(int device, ptau_timing *out) {
 
 int ptau_apply_powers_dev(int curve, int group, const void *d_in, int compressed_in, void *d_out, int compressed_out,
                           uint64_t n, uint64_t start, const uint64_t *tau, const uint64_t *coeff, int check_input,
-                          int device, char *errbuf, size_t err_len) {
+                          int batch_exp_mode, int device, char *errbuf, size_t err_len) {
     Err err{errbuf, err_len};
     const GroupOps *ops = get_ops(curve, group);
     if (!ops) return err.fail(PTAU_E_ARG, "unknown curve/group %d/%d", curve, group);
     if (!tau || (n && (!d_in || !d_out))) return err.fail(PTAU_E_ARG, "null pointer argument");
+    const int use_endo = endo_allowed(check_input, batch_exp_mode);
+    if (use_endo < 0) return err.fail(PTAU_E_ARG, "unknown batch_exp_mode %d", batch_exp_mode);
     DeviceCtx *c;
     int rc = ensure_ctx(device, c, err);
     if (rc) return rc;
@@ -850,16 +877,18 @@ int ptau_apply_powers_dev(int curve, int group, const void *d_in, int compressed
     c->timing = ptau_timing{};
     c->pending.bytes = 0;   // a copy left pending by a call that failed must never land
     return run_apply_powers_dev(c, curve, group, ops, (const uint8_t *)d_in, compressed_in, (uint8_t *)d_out, compressed_out, n, start, tau,
-                                coeff, check_input, err);
+                                coeff, check_input, use_endo, err);
 }
 
 int ptau_apply_powers(int curve, int group, const uint8_t *in, int compressed_in, uint8_t *out, int compressed_out, uint64_t n,
-                      uint64_t start, const uint64_t *tau, const uint64_t *coeff, int check_input, int device, char *errbuf,
-                      size_t err_len) {
+                      uint64_t start, const uint64_t *tau, const uint64_t *coeff, int check_input, int batch_exp_mode, int device,
+                      char *errbuf, size_t err_len) {
     Err err{errbuf, err_len};
     const GroupOps *ops = get_ops(curve, group);
     if (!ops) return err.fail(PTAU_E_ARG, "unknown curve/group %d/%d", curve, group);
     if (!tau || (n && (!in || !out))) return err.fail(PTAU_E_ARG, "null pointer argument");
+    const int use_endo = endo_allowed(check_input, batch_exp_mode);
+    if (use_endo < 0) return err.fail(PTAU_E_ARG, "unknown batch_exp_mode %d", batch_exp_mode);
     DeviceCtx *c;
     int rc = ensure_ctx(device, c, err);
     if (rc) return rc;
@@ -867,16 +896,18 @@ int ptau_apply_powers(int curve, int group, const uint8_t *in, int compressed_in
     HIP_TRY(hipSetDevice(device));
     c->timing = ptau_timing{};
     c->pending.bytes = 0;   // a copy left pending by a call that failed must never land
-    return run_apply_powers_host(c, curve, group, ops, in, compressed_in, out, compressed_out, n, start, tau, coeff, check_input, err);
+    return run_apply_powers_host(c, curve, group, ops, in, compressed_in, out, compressed_out, n, start, tau, coeff, check_input, use_endo, err);
 }
 
 int ptau_phase1_computation(const ptau_params *p, const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len,
-                            const uint64_t *tau, const uint64_t *alpha, const uint64_t *beta, int check_input, int device,
-                            char *errbuf, size_t err_len) {
+                            const uint64_t *tau, const uint64_t *alpha, const uint64_t *beta, int check_input,
+                            int batch_exp_mode, int device, char *errbuf, size_t err_len) {
     Err err{errbuf, err_len};
     int rc = check_params(p, err);
     if (rc) return rc;
     if (!in || !out || !tau || !alpha || !beta) return err.fail(PTAU_E_ARG, "null pointer argument");
+    const int use_endo = endo_allowed(check_input, batch_exp_mode);
+    if (use_endo < 0) return err.fail(PTAU_E_ARG, "unknown batch_exp_mode %d", batch_exp_mode);
     ptau_sizes sz;
     ptau_params_sizes(p, &sz);
     if (in_len != sz.accumulator_size)
@@ -909,19 +940,19 @@ int ptau_phase1_computation(const ptau_params *p, const uint8_t *in, size_t in_l
     const int curve_id = p->curve;
     auto side = std::async(std::launch::async, [=, &side_msg] {
         if (hipSetDevice(device) != hipSuccess) return (int)PTAU_E_DEVICE;
-        return run_apply_powers_host(sc, curve_id, 2, g2, pi_b, 0, po_b, 1, 1, 0, tau, beta, check_input, Err{side_msg, sizeof(side_msg)});
+        return run_apply_powers_host(sc, curve_id, 2, g2, pi_b, 0, po_b, 1, 1, 0, tau, beta, check_input, use_endo, Err{side_msg, sizeof(side_msg)});
     });
     struct SideJoin {   // the side thread never outlives the caller's buffers
         std::future<int> &f;
         ~SideJoin() { if (f.valid()) f.wait(); }
     } side_join{side};
-    if ((rc = run_apply_powers_host(c, p->curve, 1, g1, pi, 0, po, 1, n1, s, tau, nullptr, check_input, err, /*defer_copy=*/true))) return rc;
+    if ((rc = run_apply_powers_host(c, p->curve, 1, g1, pi, 0, po, 1, n1, s, tau, nullptr, check_input, use_endo, err, /*defer_copy=*/true))) return rc;
     pi += n1 * g1->uncomp; po += n1 * g1->comp;
-    if ((rc = run_apply_powers_host(c, p->curve, 2, g2, pi, 0, po, 1, n2, s, tau, nullptr, check_input, err, /*defer_copy=*/true))) return rc;
+    if ((rc = run_apply_powers_host(c, p->curve, 2, g2, pi, 0, po, 1, n2, s, tau, nullptr, check_input, use_endo, err, /*defer_copy=*/true))) return rc;
     pi += n2 * g2->uncomp; po += n2 * g2->comp;
-    if ((rc = run_apply_powers_host(c, p->curve, 1, g1, pi, 0, po, 1, n2, s, tau, alpha, check_input, err, /*defer_copy=*/true))) return rc;
+    if ((rc = run_apply_powers_host(c, p->curve, 1, g1, pi, 0, po, 1, n2, s, tau, alpha, check_input, use_endo, err, /*defer_copy=*/true))) return rc;
     pi += n2 * g1->uncomp; po += n2 * g1->comp;
-    if ((rc = run_apply_powers_host(c, p->curve, 1, g1, pi, 0, po, 1, n2, s, tau, beta, check_input, err, /*defer_copy=*/true))) return rc;
+    if ((rc = run_apply_powers_host(c, p->curve, 1, g1, pi, 0, po, 1, n2, s, tau, beta, check_input, use_endo, err, /*defer_copy=*/true))) return rc;
     pi += n2 * g1->uncomp; po += n2 * g1->comp;
     if ((rc = flush_pending_copy(c, err))) return rc;   // the last vector's deferred copy
     rc = side.get();
@@ -934,8 +965,8 @@ int ptau_contribute_file(const ptau_params *p, const char *challenge_path, const
                          const char *response_path, const char *response_hash_path, const uint64_t *tau,
                          const uint64_t *alpha, const uint64_t *beta, const uint8_t *public_key, size_t public_key_len,
                          int check_input, int batch_exp_mode, int device, char *errbuf, size_t err_len) {
-    (void)batch_exp_mode;   // every BatchExpMode value selects the same GPU path
     Err err{errbuf, err_len};
+    if (endo_allowed(check_input, batch_exp_mode) < 0) return err.fail(PTAU_E_ARG, "unknown batch_exp_mode %d", batch_exp_mode);
     int rc = check_params(p, err);
     if (rc) return rc;
     if (!challenge_path || !challenge_hash_path || !response_path || !response_hash_path || !public_key)
@@ -957,13 +988,59 @@ int ptau_contribute_file(const ptau_params *p, const char *challenge_path, const
         const uint8_t *chp = (const uint8_t *)ch.p;
         const size_t chl = ch.len;
         auto fut = std::async(std::launch::async, [chp, chl, &digest] { ptau_blake2b512(chp, chl, digest); });
-        rc = ptau_phase1_computation(p, chp, chl, out, resp.len, tau, alpha, beta, check_input, device, errbuf, err_len);
+        rc = ptau_phase1_computation(p, chp, chl, out, resp.len, tau, alpha, beta, check_input, batch_exp_mode, device, errbuf, err_len);
         fut.get();
         if (rc) return rc;
     }
     if ((rc = write_small_file(challenge_hash_path, digest, 64, err))) return rc;
     memcpy(out, digest, 64);
     memcpy(out + sz.contribution_size - sz.public_key_size, public_key, public_key_len);
+    ptau_blake2b512(out, resp.len, digest);
+    if (msync(resp.p, resp.len, MS_SYNC)) return err.fail(PTAU_E_IO, "msync failed: %s", strerror(errno));
+    return write_small_file(response_hash_path, digest, 64, err);
+}
+
+int ptau_contribute_file_seeded(const ptau_params *p, const char *challenge_path, const char *challenge_hash_path,
+                                const char *response_path, const char *response_hash_path, const uint8_t *seed, size_t seed_len,
+                                int check_input, int batch_exp_mode, int device, char *errbuf, size_t err_len) {
+    Err err{errbuf, err_len};
+    int rc = check_params(p, err);
+    if (rc) return rc;
+    if (!challenge_path || !challenge_hash_path || !response_path || !response_hash_path || !seed)
+        return err.fail(PTAU_E_ARG, "null pointer argument");
+    if (endo_allowed(check_input, batch_exp_mode) < 0) return err.fail(PTAU_E_ARG, "unknown batch_exp_mode %d", batch_exp_mode);
+    ptau_sizes sz;
+    ptau_params_sizes(p, &sz);
+    // PrivateKey first: tau, alpha, beta are the generator's first draws and do not depend on the challenge digest
+    uint64_t tau[12], alpha[12], beta[12];
+    if ((rc = ptau_private_key_from_seed(p->curve, seed, seed_len, tau, alpha, beta, errbuf, err_len))) return rc;
+    MappedFile ch, resp;
+    if ((rc = ch.open_ro(challenge_path, err))) return rc;
+    if (ch.len != sz.accumulator_size)
+        return err.fail(PTAU_E_LEN, "challenge file is %zu bytes, parameters require %llu", ch.len,
+                        (unsigned long long)sz.accumulator_size);
+    if ((rc = resp.create_new(response_path, sz.contribution_size, err))) return rc;
+    uint8_t *out = (uint8_t *)resp.p;
+    uint8_t digest[64];
+    std::vector<uint8_t> pk(sz.public_key_size);
+    {   // host thread: BLAKE2b(challenge), then the PublicKey bound to it — both while the GPU updates the elements
+        const uint8_t *chp = (const uint8_t *)ch.p;
+        const size_t chl = ch.len;
+        const int curve = p->curve;
+        char kmsg[256] = {0};
+        auto fut = std::async(std::launch::async, [&, chp, chl, curve] {
+            ptau_blake2b512(chp, chl, digest);
+            uint64_t t2[12], a2[12], b2[12];
+            return ptau_key_generation(curve, seed, seed_len, digest, t2, a2, b2, pk.data(), pk.size(), kmsg, sizeof(kmsg));
+        });
+        rc = ptau_phase1_computation(p, chp, chl, out, resp.len, tau, alpha, beta, check_input, batch_exp_mode, device, errbuf, err_len);
+        const int krc = fut.get();
+        if (rc) return rc;
+        if (krc) return err.fail(krc, "key generation: %s", kmsg);
+    }
+    if ((rc = write_small_file(challenge_hash_path, digest, 64, err))) return rc;
+    memcpy(out, digest, 64);
+    memcpy(out + sz.contribution_size - sz.public_key_size, pk.data(), pk.size());
     ptau_blake2b512(out, resp.len, digest);
     if (msync(resp.p, resp.len, MS_SYNC)) return err.fail(PTAU_E_IO, "msync failed: %s", strerror(errno));
     return write_small_file(response_hash_path, digest, 64, err);
@@ -1032,14 +1109,128 @@ struct VerifyDigests {
     uint8_t challenge[64], response[64], new_challenge[64];
 };
 
+// bit 6 of the last byte of an uncompressed point = arkworks' infinity flag
+__global__ void __launch_bounds__(256) infinity_flag_kernel(const uint8_t *__restrict__ in, uint64_t n, uint32_t stride, int *__restrict__ err) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (in[(i + 1) * stride - 1] & 0x40u) atomicOr(err, ptau::ERRBIT_INFINITY);
+}
+
+// CheckForCorrectness of one CHALLENGE vector (uncompressed host bytes): bit 0 = no point at infinity, bit 1 = on the
+// curve and in the prime-order subgroup.  check_input of transform_pok_and_correctness (--force-correctness-checks,
+// /root/reference/src/bin/contribute.rs:133, 971-974).  Caller holds the device mutex.
+int run_check_input_vector(DeviceCtx *c, int curve, int group, const GroupOps *ops, const uint8_t *in, uint64_t n, int check_input,
+                           const Err &err) {
+    if (!n || !(check_input & 3)) return PTAU_OK;
+    int rc;
+    if ((rc = grow(c->d_in, c->in_cap, n * ops->uncomp, err))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_in, in, n * ops->uncomp, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
+    if (check_input & 1)
+        hipLaunchKernelGGL(infinity_flag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const uint8_t *)c->d_in, n,
+                           (uint32_t)ops->uncomp, c->d_err);
+    if ((check_input & 2) && (rc = enqueue_subgroup_kernels(c, curve, group, ops, (const uint8_t *)c->d_in, 0, n, err))) return rc;
+    int bits = 0;
+    HIP_TRY(hipMemcpyAsync(&bits, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    if (check_input & 2) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+        c->timing.kernel_ms += ms;
+        c->timing.subgroup_ms += ms;
+    }
+    c->timing.points += n;
+    return errbits_to_code(bits, err);
+}
+
+// One same-ratio job of the host pairing tail; run_ratio_jobs runs them on one host thread each and reports the first
+// failure in job order (so the error a caller sees does not depend on thread timing).
+struct RatioJob {
+    const uint8_t *a, *b, *c2, *d2;   // (a, b) in G1, (c2, d2) in G2, all uncompressed
+    std::string what;                  // message when the ratios differ
+};
+int run_ratio_jobs(int curve, const std::vector<RatioJob> &jobs, const Err &err) {
+    std::vector<std::future<int>> futs;
+    for (auto &j : jobs)
+        futs.push_back(std::async(std::launch::async, [curve, &j] { return ptau_check_same_ratio(curve, j.a, j.b, j.c2, j.d2, nullptr, 0); }));
+    int bad_rc = PTAU_OK;
+    size_t bad = 0;
+    for (size_t i = 0; i < futs.size(); i++) {
+        const int r = futs[i].get();
+        if (r && !bad_rc) { bad_rc = r; bad = i; }
+    }
+    if (bad_rc == PTAU_E_INVALID_RATIO) return err.fail(bad_rc, "%s", jobs[bad].what.c_str());
+    if (bad_rc) return err.fail(bad_rc, "malformed point in the same-ratio check: %s", jobs[bad].what.c_str());
+    return PTAU_OK;
+}
+
+// Phase1::verification steps (1)-(2): the jobs of the three proofs of knowledge and, for chunk 0 / Full mode, of the
+// before/after checks.  `scratch` keeps the few decompressed response elements alive until the jobs have run.
+int collect_pok_jobs(const ptau_params *p, const ptau_sizes &sz, const uint8_t *challenge, const uint8_t *response,
+                     const uint8_t *g2_s, std::vector<uint8_t> &scratch, std::vector<RatioJob> &jobs, const Err &err) {
+    const GroupOps *g1 = get_ops(p->curve, 1), *g2 = get_ops(p->curve, 2);
+    const size_t u1 = g1->uncomp, u2 = g2->uncomp;
+    // PublicKey (uncompressed): tau_g1.0, tau_g1.1, alpha_g1.0, alpha_g1.1, beta_g1.0, beta_g1.1, tau_g2, alpha_g2, beta_g2
+    const uint8_t *pk = response + sz.contribution_size - sz.public_key_size;
+    const uint8_t *pk_g1[3][2], *pk_g2[3];
+    for (int x = 0; x < 3; x++) {
+        pk_g1[x][0] = pk + (2 * x) * u1;
+        pk_g1[x][1] = pk + (2 * x + 1) * u1;
+        pk_g2[x] = pk + 6 * u1 + x * u2;
+    }
+    static const char *names[3] = {"tau", "alpha", "beta"};
+    // (1) proofs of knowledge: (g1_s, x*g1_s) ~ (g2_s, x*g2_s)
+    for (int x = 0; x < 3; x++)
+        jobs.push_back({pk_g1[x][0], pk_g1[x][1], g2_s + x * u2, pk_g2[x], std::string("proof of knowledge of ") + names[x] + " is invalid"});
+    if (!(p->contribution_mode == PTAU_MODE_FULL || p->chunk_index == 0)) return PTAU_OK;
+    // (2) chunk 0: the response extends the challenge by exactly the key in the public key.
+    //     Needs a handful of response elements decompressed: done on the host (sqrt of ~5 points).
+    const uint64_t n1 = sz.g1_chunk_size, n2 = sz.other_chunk_size;
+    if (n1 < 2 || n2 < 2) return err.fail(PTAU_E_ARG, "chunk 0 too small for the before/after checks");
+    const uint8_t *b_tau_g1 = challenge + 64, *b_tau_g2 = b_tau_g1 + n1 * u1, *b_alpha = b_tau_g2 + n2 * u2,
+                  *b_beta = b_alpha + n2 * u1, *b_beta_g2 = b_beta + n2 * u1;
+    const size_t c1 = g1->comp, c2 = g2->comp;
+    const uint8_t *a_tau_g1 = response + 64, *a_tau_g2 = a_tau_g1 + n1 * c1, *a_alpha = a_tau_g2 + n2 * c2,
+                  *a_beta = a_alpha + n2 * c1, *a_beta_g2 = a_beta + n2 * c1;
+    scratch.assign(2 * u1 + u1 + u1 + 2 * u2 + u2, 0);
+    uint8_t *da_tau_g1 = scratch.data(), *da_alpha = da_tau_g1 + 2 * u1, *da_beta = da_alpha + u1, *da_tau_g2 = da_beta + u1,
+            *da_beta_g2 = da_tau_g2 + 2 * u2;
+    {   // five elements: host-side sqrt (the pairing tail needs no GPU)
+        int bad = g1->decompress_host(a_tau_g1, da_tau_g1, 2, 1) | g1->decompress_host(a_alpha, da_alpha, 1, 1) |
+                  g1->decompress_host(a_beta, da_beta, 1, 1) | g2->decompress_host(a_tau_g2, da_tau_g2, 2, 1) |
+                  g2->decompress_host(a_beta_g2, da_beta_g2, 1, 1);
+        int rc;
+        if ((rc = errbits_to_code(bad, err))) return rc;
+    }
+    // element 0 (tau^0) must be untouched
+    if (memcmp(da_tau_g1, b_tau_g1, u1) != 0 || memcmp(da_tau_g2, b_tau_g2, u2) != 0)
+        return err.fail(PTAU_E_INVALID_RATIO, "element 0 of tau_g1 / tau_g2 changed");
+    struct { const uint8_t *before, *after; int key; bool g1; const char *what; } chk[5] = {
+        {b_tau_g1 + u1, da_tau_g1 + u1, 0, true, "tau_g1[1]"}, {b_alpha, da_alpha, 1, true, "alpha_g1[0]"},
+        {b_beta, da_beta, 2, true, "beta_g1[0]"},             {b_tau_g2 + u2, da_tau_g2 + u2, 0, false, "tau_g2[1]"},
+        {b_beta_g2, da_beta_g2, 2, false, "beta_g2"}};
+    for (auto &k : chk) {
+        const std::string what = std::string(k.what) + " was not multiplied by the key in the public key";
+        if (k.g1) jobs.push_back({k.before, k.after, g2_s + k.key * u2, pk_g2[k.key], what});
+        else jobs.push_back({pk_g1[k.key][0], pk_g1[k.key][1], k.before, k.after, what});
+    }
+    return PTAU_OK;
+}
+
+// verify_pok: 0 = element checks only; 1 = Phase1::verification in full (proofs of knowledge + chunk-0 checks), with
+// g2_s = the caller's three compute_g2_s points or, when NULL, derived here from BLAKE2b(challenge) and the public key.
 int verify_chunk_impl(const ptau_params *p, const uint8_t *challenge, size_t challenge_len, const uint8_t *response,
                       size_t response_len, uint8_t *new_challenge, size_t new_challenge_len, int check_input,
-                      int check_output, int subgroup_check_mode, int ratio_check, const uint8_t *tau_g2_check,
-                      int device, VerifyDigests *digests, char *errbuf, size_t err_len) {
+                      int check_output, int subgroup_check_mode, int ratio_check, int verify_pok, const uint8_t *g2_s,
+                      const uint8_t *tau_g2_check, int device, VerifyDigests *digests, char *errbuf, size_t err_len) {
     Err err{errbuf, err_len};
     int rc = check_params(p, err);
     if (rc) return rc;
     if (!challenge || !response || !new_challenge) return err.fail(PTAU_E_ARG, "null pointer argument");
+    if (check_input < 0 || check_input > 3 || check_output < 0 || check_output > 3)
+        return err.fail(PTAU_E_ARG, "unknown CheckForCorrectness value %d / %d", check_input, check_output);
+    if (subgroup_check_mode < 0 || subgroup_check_mode > 3) return err.fail(PTAU_E_ARG, "unknown subgroup check mode %d", subgroup_check_mode);
     ptau_sizes sz;
     ptau_params_sizes(p, &sz);
     if (challenge_len != sz.accumulator_size || new_challenge_len != sz.accumulator_size)
@@ -1050,11 +1241,11 @@ int verify_chunk_impl(const ptau_params *p, const uint8_t *challenge, size_t cha
     // hash chain: response[0..64) must be BLAKE2b(challenge); new_challenge starts with BLAKE2b(response).
     // Both digests run on host threads WHILE the GPU checks the elements (BLAKE2b is sequential, ~1 GB/s/core,
     // and would otherwise cost as much as the device work — SURVEY §7 hard part 7).
-    auto fut_chain = std::async(std::launch::async, [=] {
-        uint8_t d[64];
-        ptau_blake2b512(challenge, challenge_len, d);
-        if (digests) memcpy(digests->challenge, d, 64);
-        return memcmp(d, response, 64) == 0;
+    uint8_t chal_digest[64];
+    auto fut_chain = std::async(std::launch::async, [=, &chal_digest] {
+        ptau_blake2b512(challenge, challenge_len, chal_digest);
+        if (digests) memcpy(digests->challenge, chal_digest, 64);
+        return memcmp(chal_digest, response, 64) == 0;
     });
     std::shared_future<void> fut_resp = std::async(std::launch::async, [=] {
         ptau_blake2b512(response, response_len, new_challenge);
@@ -1100,12 +1291,18 @@ int verify_chunk_impl(const ptau_params *p, const uint8_t *challenge, size_t cha
     HIP_TRY(hipSetDevice(device));
     c->timing = ptau_timing{};
     c->pending.bytes = 0;   // a copy left pending by a call that failed must never land
-    (void)check_input;   // DEFAULT_VERIFY_CHECK_INPUT_CORRECTNESS = No: the challenge was produced by this verifier
     const uint64_t n1 = sz.g1_chunk_size, n2 = sz.other_chunk_size;
     const uint8_t *pi = response + 64;
     uint8_t *po = new_challenge + 64;
     struct { const GroupOps *ops; int group; uint64_t n; const char *name; } vec[5] = {
         {g1, 1, n1, "tau_g1"}, {g2, 2, n2, "tau_g2"}, {g1, 1, n2, "alpha_g1"}, {g1, 1, n2, "beta_g1"}, {g2, 2, 1, "beta_g2"}};
+    if (check_input & 3) {   // CheckForCorrectness of the challenge elements (DEFAULT_VERIFY_CHECK_INPUT_CORRECTNESS is No)
+        const uint8_t *pc = challenge + 64;
+        for (auto &v : vec) {
+            if ((rc = run_check_input_vector(c, p->curve, v.group, v.ops, pc, v.n, check_input, err))) return rc;
+            pc += v.n * v.ops->uncomp;
+        }
+    }
     uint64_t seed[2] = {0, 0};
     if (ratio_check) {   // fresh secret for the random linear combinations of this verification
         FILE *f = fopen("/dev/urandom", "rb");
@@ -1144,42 +1341,53 @@ int verify_chunk_impl(const ptau_params *p, const uint8_t *challenge, size_t cha
     po += g2->uncomp;
     nc_ready.store((size_t)(po - new_challenge), std::memory_order_release);
     lk.unlock();   // another lane may use the device while this one finishes its host tail
+    // ---- host tail: every same-ratio check of this verification, one host thread each ----
+    std::vector<RatioJob> ratio_jobs, pok_jobs;
     if (ratio_check) {
         // check_power_ratios: consecutive elements of every vector differ by the SAME factor tau, i.e.
         // (sum rho_i v_i, sum rho_i v_{i+1}) has the ratio of (tauG2[j], tauG2[j+1]) resp. (tauG1[j], tauG1[j+1]).
-        const uint8_t *g2_pair = nullptr, *g1_pair = n1 >= 2 ? vec_out[0] : nullptr;
-        if (n2 >= 2) g2_pair = vec_out[1];
-        else if (tau_g2_check) g2_pair = tau_g2_check;
-        if (!g2_pair)
-            return err.fail(PTAU_E_ARG, "ratio_check on a chunk without tauG2 elements needs tau_g2_check (tauG2[0], tauG2[1])");
-        // the (up to four) pairing checks are independent: one host thread each
-        struct Job { const uint8_t *a, *b, *c2, *d2; const char *name; };
-        std::vector<Job> jobs;
-        for (int k : {0, 2, 3}) {
-            if (vec[k].n < 2) continue;
-            const uint8_t *pa = pairs.data() + (size_t)k * 2 * g2->uncomp;
-            jobs.push_back({pa, pa + g2->uncomp, g2_pair, g2_pair + g2->uncomp, vec[k].name});
-        }
+        // A chunk without tauG2 elements (start >= 2^power) holds no G2 pair of ratio tau in its own files: its tauG1
+        // power ratios are then checked only when the caller supplies tau_g2_check, and are otherwise left to the
+        // full-length check of transform_ratios on the combined accumulator (control.rs:587-591) — an honest response
+        // never fails here for lack of it.
+        const uint8_t *g2_pair = n2 >= 2 ? vec_out[1] : tau_g2_check, *g1_pair = n1 >= 2 ? vec_out[0] : nullptr;
+        if (g2_pair)
+            for (int k : {0, 2, 3}) {
+                if (vec[k].n < 2) continue;
+                const uint8_t *pa = pairs.data() + (size_t)k * 2 * g2->uncomp;
+                ratio_jobs.push_back({pa, pa + g2->uncomp, g2_pair, g2_pair + g2->uncomp, std::string("power ratio check failed for ") + vec[k].name});
+            }
         if (n2 >= 2 && g1_pair) {
             const uint8_t *pa = pairs.data() + (size_t)1 * 2 * g2->uncomp;
-            jobs.push_back({g1_pair, g1_pair + g1->uncomp, pa, pa + g2->uncomp, "tau_g2"});
+            ratio_jobs.push_back({g1_pair, g1_pair + g1->uncomp, pa, pa + g2->uncomp, "power ratio check failed for tau_g2"});
         }
-        std::vector<std::future<int>> futs;
-        const int curve = p->curve;
-        for (auto &j : jobs)
-            futs.push_back(std::async(std::launch::async, [curve, j] { return ptau_check_same_ratio(curve, j.a, j.b, j.c2, j.d2, nullptr, 0); }));
-        int bad_rc = PTAU_OK;
-        const char *bad_name = nullptr;
-        for (size_t i = 0; i < futs.size(); i++) {
-            int r = futs[i].get();
-            if (r && !bad_rc) { bad_rc = r; bad_name = jobs[i].name; }
-        }
-        if (bad_rc == PTAU_E_INVALID_RATIO) return err.fail(bad_rc, "power ratio check failed for %s", bad_name);
-        if (bad_rc) return err.fail(bad_rc, "malformed ratio pair for %s", bad_name);
     }
+    // the power-ratio pairings start at once; the proofs of knowledge are bound to BLAKE2b(challenge) and wait for it
+    char ratio_msg[256] = {0};
+    const int curve_id = p->curve;
+    auto fut_ratio = std::async(std::launch::async, [&ratio_jobs, &ratio_msg, curve_id] {
+        return run_ratio_jobs(curve_id, ratio_jobs, Err{ratio_msg, sizeof(ratio_msg)});
+    });
+    struct RatioJoin {   // the pairing threads read `pairs` and the caller's buffers
+        std::future<int> &f;
+        ~RatioJoin() { if (f.valid()) f.wait(); }
+    } ratio_join{fut_ratio};
+    std::vector<uint8_t> pok_scratch, g2_s_own;
+    const bool chain_ok = fut_chain.get();
+    if (verify_pok) {
+        if (!g2_s) {
+            g2_s_own.resize(3 * (size_t)g2->uncomp);
+            const uint8_t *pk = response + sz.contribution_size - sz.public_key_size;
+            if ((rc = ptau_compute_g2_s(p->curve, chal_digest, pk, sz.public_key_size, g2_s_own.data(), errbuf, err_len))) return rc;
+            g2_s = g2_s_own.data();
+        }
+        if ((rc = collect_pok_jobs(p, sz, challenge, response, g2_s, pok_scratch, pok_jobs, err))) return rc;
+        if ((rc = run_ratio_jobs(p->curve, pok_jobs, err))) return rc;
+    }
+    if ((rc = fut_ratio.get())) return err.fail(rc, "%s", ratio_msg);
     // new_challenge = BLAKE2b(response) | decompressed elements
     fut_resp.wait();
-    if (!fut_chain.get())
+    if (!chain_ok)
         return err.fail(PTAU_E_HASH_CHAIN, "response does not start with the hash of the challenge it claims to extend");
     joiner.ok = true;
     if (fut_nc.valid()) fut_nc.wait();
@@ -1191,17 +1399,18 @@ extern "C" {
 
 int ptau_verify_chunk(const ptau_params *p, const uint8_t *challenge, size_t challenge_len, const uint8_t *response,
                       size_t response_len, uint8_t *new_challenge, size_t new_challenge_len, int check_input,
-                      int check_output, int subgroup_check_mode, int ratio_check, const uint8_t *tau_g2_check,
-                      int device, char *errbuf, size_t err_len) {
+                      int check_output, int subgroup_check_mode, int ratio_check, int verify_pok, const uint8_t *g2_s,
+                      const uint8_t *tau_g2_check, int device, char *errbuf, size_t err_len) {
     return verify_chunk_impl(p, challenge, challenge_len, response, response_len, new_challenge, new_challenge_len, check_input,
-                             check_output, subgroup_check_mode, ratio_check, tau_g2_check, device, nullptr, errbuf, err_len);
+                             check_output, subgroup_check_mode, ratio_check, verify_pok, g2_s, tau_g2_check, device, nullptr, errbuf,
+                             err_len);
 }
 
 int ptau_transform_pok_and_correctness_file(const ptau_params *p, const char *challenge_path, const char *challenge_hash_path,
                                             int check_input, const char *response_path, const char *response_hash_path,
                                             int check_output, const char *new_challenge_path,
                                             const char *new_challenge_hash_path, int subgroup_check_mode, int ratio_check,
-                                            const uint8_t *tau_g2_check, int device, char *errbuf, size_t err_len) {
+                                            const uint8_t *g2_s, int device, char *errbuf, size_t err_len) {
     Err err{errbuf, err_len};
     int rc = check_params(p, err);
     if (rc) return rc;
@@ -1219,7 +1428,7 @@ int ptau_transform_pok_and_correctness_file(const ptau_params *p, const char *ch
     if ((rc = nc.create_new(new_challenge_path, sz.accumulator_size, err))) return rc;
     VerifyDigests dg;
     rc = verify_chunk_impl(p, (const uint8_t *)ch.p, ch.len, (const uint8_t *)resp.p, resp.len, (uint8_t *)nc.p, nc.len, check_input,
-                           check_output, subgroup_check_mode, ratio_check, tau_g2_check, device, &dg, errbuf, err_len);
+                           check_output, subgroup_check_mode, ratio_check, /*verify_pok=*/1, g2_s, nullptr, device, &dg, errbuf, err_len);
     // the reference writes challenge.hash and response.hash before it verifies: keep them on the failure paths that got that far
     if (rc == PTAU_OK || rc == PTAU_E_HASH_CHAIN || rc == PTAU_E_INVALID_RATIO || rc == PTAU_E_NOT_IN_SUBGROUP ||
         rc == PTAU_E_POINT_AT_INFINITY || rc == PTAU_E_POINT) {
@@ -1318,33 +1527,61 @@ static const unsigned char *generator_bytes(int curve, int group) {
     switch (curve * 2 + (group - 1)) {
     case 0: return G::BLS_G1;   case 1: return G::BLS_G2;
     case 2: return G::BW6_G1;   case 3: return G::BW6_G2;
-    case 4: return G::MNT4_G1;  case 5: return G::MNT4_G2;
-    case 6: return G::MNT6_G1;  case 7: return G::MNT6_G2;
+    case 4: return G::MNT4_G1;  // MNT G2: not built in (see ptau_new_challenge)
+    case 6: return G::MNT6_G1;
     }
     return nullptr;
+}
+
+// Phase1::initialization with the two generators supplied by the caller (uncompressed arkworks bytes of
+// G1Affine::generator() / G2Affine::generator()): the accumulator is bit-exact with the reference's by construction.
+int ptau_new_challenge_with_generators(const ptau_params *p, const uint8_t *g1_generator, const uint8_t *g2_generator, uint8_t *out,
+                                       size_t out_len, char *errbuf, size_t err_len) {
+    Err err{errbuf, err_len};
+    int rc = check_params(p, err);
+    if (rc) return rc;
+    if (!g1_generator || !g2_generator) return err.fail(PTAU_E_ARG, "null pointer argument");
+    ptau_sizes sz;
+    ptau_params_sizes(p, &sz);
+    if (!out || out_len != sz.accumulator_size)
+        return err.fail(PTAU_E_LEN, "challenge buffer must be %llu bytes", (unsigned long long)sz.accumulator_size);
+    const GroupOps *g1 = get_ops(p->curve, 1), *g2 = get_ops(p->curve, 2);
+    ptau_blake2b512(nullptr, 0, out);   // blank hash: the initial challenge extends nothing
+    uint8_t *po = out + 64;
+    auto fill = [&](const uint8_t *pt, int size, uint64_t n) {
+        for (uint64_t i = 0; i < n; i++, po += size) memcpy(po, pt, size);
+    };
+    fill(g1_generator, g1->uncomp, sz.g1_chunk_size);
+    fill(g2_generator, g2->uncomp, sz.other_chunk_size);
+    fill(g1_generator, g1->uncomp, sz.other_chunk_size);
+    fill(g1_generator, g1->uncomp, sz.other_chunk_size);
+    fill(g2_generator, g2->uncomp, 1);
+    return PTAU_OK;
+}
+
+int ptau_generator(int curve, int group, uint8_t *out, size_t out_len, char *errbuf, size_t err_len) {
+    Err err{errbuf, err_len};
+    const GroupOps *ops = get_ops(curve, group);
+    if (!ops) return err.fail(PTAU_E_ARG, "unknown curve/group %d/%d", curve, group);
+    if (!out || out_len != (size_t)ops->uncomp) return err.fail(PTAU_E_LEN, "generator buffer must be %d bytes", ops->uncomp);
+    if (group == PTAU_G2 && (curve == PTAU_CURVE_MNT4_753 || curve == PTAU_CURVE_MNT6_753))
+        return err.fail(PTAU_E_UNSUPPORTED, "the arkworks G2 generator of this curve is not built in: pass G2Affine::generator() "
+                                            "through ptau_new_challenge_with_generators");
+    memcpy(out, generator_bytes(curve, group), ops->uncomp);
+    return PTAU_OK;
 }
 
 int ptau_new_challenge(const ptau_params *p, uint8_t *out, size_t out_len, char *errbuf, size_t err_len) {
     Err err{errbuf, err_len};
     int rc = check_params(p, err);
     if (rc) return rc;
-    ptau_sizes sz;
-    ptau_params_sizes(p, &sz);
-    if (!out || out_len != sz.accumulator_size)
-        return err.fail(PTAU_E_LEN, "challenge buffer must be %llu bytes", (unsigned long long)sz.accumulator_size);
-    const GroupOps *g1 = get_ops(p->curve, 1), *g2 = get_ops(p->curve, 2);
-    const unsigned char *b1 = generator_bytes(p->curve, 1), *b2 = generator_bytes(p->curve, 2);
-    ptau_blake2b512(nullptr, 0, out);   // blank hash: the initial challenge extends nothing
-    uint8_t *po = out + 64;
-    auto fill = [&](const unsigned char *pt, int size, uint64_t n) {
-        for (uint64_t i = 0; i < n; i++, po += size) memcpy(po, pt, size);
-    };
-    fill(b1, g1->uncomp, sz.g1_chunk_size);
-    fill(b2, g2->uncomp, sz.other_chunk_size);
-    fill(b1, g1->uncomp, sz.other_chunk_size);
-    fill(b1, g1->uncomp, sz.other_chunk_size);
-    fill(b2, g2->uncomp, 1);
-    return PTAU_OK;
+    // MNT4-753 / MNT6-753: ark-mnt4-753 / ark-mnt6-753's G2 generator constants are not recoverable offline (DESIGN.md
+    // §2) — an accumulator built from any other generator would NOT be the reference's initial challenge, so the built-in
+    // form refuses; the Rust host passes its own G2Affine::generator() through ptau_new_challenge_with_generators.
+    if (p->curve == PTAU_CURVE_MNT4_753 || p->curve == PTAU_CURVE_MNT6_753)
+        return err.fail(PTAU_E_UNSUPPORTED, "new_challenge on MNT4-753 / MNT6-753 needs the arkworks G2 generator: use "
+                                            "ptau_new_challenge_with_generators");
+    return ptau_new_challenge_with_generators(p, generator_bytes(p->curve, 1), generator_bytes(p->curve, 2), out, out_len, errbuf, err_len);
 }
 
 int ptau_new_challenge_file(const ptau_params *p, const char *challenge_path, const char *challenge_hash_path, char *errbuf,
@@ -1472,61 +1709,25 @@ int ptau_verify_pok(const ptau_params *p, const uint8_t *challenge, size_t chall
     Err err{errbuf, err_len};
     int rc = check_params(p, err);
     if (rc) return rc;
-    if (!challenge || !response || !g2_s) return err.fail(PTAU_E_ARG, "null pointer argument");
+    if (!challenge || !response) return err.fail(PTAU_E_ARG, "null pointer argument");
     ptau_sizes sz;
     ptau_params_sizes(p, &sz);
     if (challenge_len != sz.accumulator_size || response_len != sz.contribution_size)
         return err.fail(PTAU_E_LEN, "challenge/response sizes do not match the parameters");
-    const GroupOps *g1 = get_ops(p->curve, 1), *g2 = get_ops(p->curve, 2);
-    const size_t u1 = g1->uncomp, u2 = g2->uncomp;
-    // PublicKey (uncompressed): tau_g1.0, tau_g1.1, alpha_g1.0, alpha_g1.1, beta_g1.0, beta_g1.1, tau_g2, alpha_g2, beta_g2
-    const uint8_t *pk = response + sz.contribution_size - sz.public_key_size;
-    const uint8_t *pk_g1[3][2], *pk_g2[3];
-    for (int x = 0; x < 3; x++) {
-        pk_g1[x][0] = pk + (2 * x) * u1;
-        pk_g1[x][1] = pk + (2 * x + 1) * u1;
-        pk_g2[x] = pk + 6 * u1 + x * u2;
+    std::vector<uint8_t> own;
+    if (!g2_s) {   // derive the three compute_g2_s points from BLAKE2b(challenge) and the public key
+        uint8_t digest[64];
+        ptau_blake2b512(challenge, challenge_len, digest);
+        own.resize(3 * (size_t)get_ops(p->curve, 2)->uncomp);
+        if ((rc = ptau_compute_g2_s(p->curve, digest, response + sz.contribution_size - sz.public_key_size, sz.public_key_size, own.data(),
+                                    errbuf, err_len)))
+            return rc;
+        g2_s = own.data();
     }
-    static const char *names[3] = {"tau", "alpha", "beta"};
-    // (1) proofs of knowledge: (g1_s, x*g1_s) ~ (g2_s, x*g2_s)
-    for (int x = 0; x < 3; x++) {
-        rc = ptau_check_same_ratio(p->curve, pk_g1[x][0], pk_g1[x][1], g2_s + x * u2, pk_g2[x], errbuf, err_len);
-        if (rc == PTAU_E_INVALID_RATIO) return err.fail(rc, "proof of knowledge of %s is invalid", names[x]);
-        if (rc) return rc;
-    }
-    if (!(p->contribution_mode == PTAU_MODE_FULL || p->chunk_index == 0)) return PTAU_OK;
-    // (2) chunk 0: the response extends the challenge by exactly the key in the public key.
-    //     Needs a handful of response elements decompressed: done on the host (sqrt of ~5 points).
-    const uint64_t n1 = sz.g1_chunk_size, n2 = sz.other_chunk_size;
-    if (n1 < 2 || n2 < 2) return err.fail(PTAU_E_ARG, "chunk 0 too small for the before/after checks");
-    const uint8_t *b_tau_g1 = challenge + 64, *b_tau_g2 = b_tau_g1 + n1 * u1, *b_alpha = b_tau_g2 + n2 * u2,
-                  *b_beta = b_alpha + n2 * u1, *b_beta_g2 = b_beta + n2 * u1;
-    const size_t c1 = g1->comp, c2 = g2->comp;
-    const uint8_t *a_tau_g1 = response + 64, *a_tau_g2 = a_tau_g1 + n1 * c1, *a_alpha = a_tau_g2 + n2 * c2,
-                  *a_beta = a_alpha + n2 * c1, *a_beta_g2 = a_beta + n2 * c1;
-    std::vector<uint8_t> d(2 * u1 + u1 + u1 + 2 * u2 + u2);
-    uint8_t *da_tau_g1 = d.data(), *da_alpha = da_tau_g1 + 2 * u1, *da_beta = da_alpha + u1, *da_tau_g2 = da_beta + u1,
-            *da_beta_g2 = da_tau_g2 + 2 * u2;
-    {   // five elements: host-side sqrt (the pairing tail needs no GPU)
-        int bad = g1->decompress_host(a_tau_g1, da_tau_g1, 2, 1) | g1->decompress_host(a_alpha, da_alpha, 1, 1) |
-                  g1->decompress_host(a_beta, da_beta, 1, 1) | g2->decompress_host(a_tau_g2, da_tau_g2, 2, 1) |
-                  g2->decompress_host(a_beta_g2, da_beta_g2, 1, 1);
-        if ((rc = errbits_to_code(bad, err))) return rc;
-    }
-    // element 0 (tau^0) must be untouched
-    if (memcmp(da_tau_g1, b_tau_g1, u1) != 0 || memcmp(da_tau_g2, b_tau_g2, u2) != 0)
-        return err.fail(PTAU_E_INVALID_RATIO, "element 0 of tau_g1 / tau_g2 changed");
-    struct { const uint8_t *before, *after; int key; bool g1; const char *what; } chk[5] = {
-        {b_tau_g1 + u1, da_tau_g1 + u1, 0, true, "tau_g1[1]"}, {b_alpha, da_alpha, 1, true, "alpha_g1[0]"},
-        {b_beta, da_beta, 2, true, "beta_g1[0]"},             {b_tau_g2 + u2, da_tau_g2 + u2, 0, false, "tau_g2[1]"},
-        {b_beta_g2, da_beta_g2, 2, false, "beta_g2"}};
-    for (auto &k : chk) {
-        if (k.g1) rc = ptau_check_same_ratio(p->curve, k.before, k.after, g2_s + k.key * u2, pk_g2[k.key], errbuf, err_len);
-        else rc = ptau_check_same_ratio(p->curve, pk_g1[k.key][0], pk_g1[k.key][1], k.before, k.after, errbuf, err_len);
-        if (rc == PTAU_E_INVALID_RATIO) return err.fail(rc, "%s was not multiplied by the key in the public key", k.what);
-        if (rc) return rc;
-    }
-    return PTAU_OK;
+    std::vector<uint8_t> scratch;
+    std::vector<RatioJob> jobs;
+    if ((rc = collect_pok_jobs(p, sz, challenge, response, g2_s, scratch, jobs, err))) return rc;
+    return run_ratio_jobs(p->curve, jobs, err);
 }
 
 }  // extern "C"

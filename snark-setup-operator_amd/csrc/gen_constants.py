@@ -22,16 +22,42 @@ BLS_G2_B1 = 15519865560778145640639164021693612012183610765294879632393055760003
 RADIX29 = {"BlsFq", "Mnt4Fq", "Mnt6Fq"}
 
 
-# Synthetic order-r generators of the MNT twists (arkworks' constants are not recoverable offline):
-# smallest x = (k, 1[, 0]) on the twist, positive y, times the twist cofactor.
-MNT4_G2_GEN = ((19241021068095916780101505819204177866130316978498813175655453712234130792249572965936095408402742213223103260192441262888439414276965921531944942609754704672828990156287074618460540748574980646193593053348672676196473455297449, 37571968813056719349544804613609395755526305787839452593162691811172225578825852772050144361134352258939844287959560550034749844248343755134490338394667988539186355728895970457865941785683187620473448787127897942455665248375551), (23589630296873363831863652409442990017701166326539432024402785959446586334761491637547954312091039409900945953790575465129293333033671016576994774274066633181161735894331556574134695169051050976686432562161446479591360416615138, 20185621173490135311277358674180003121685302588984477921495339599873814308952582489044294387122623024266086590616061119415679839539450996087397501791402712466898936321241372074236777219971432749676198243752018672254846680537991))
-MNT6_G2_GEN = ((29198358678412327442734962858329560226529221072203506456026012448974205216981182326430452963416355393639268348853246220872774645199447843650057899436615551635917170214459877469820960613629590429199233247184212848085187308734929, 5999018000412277550478365752247211689696853783805982998351836252998281861610577852123252644775525980463600111418780194099963317946867954670821792886908172141813419565404494811506209266206591269999903100596739427595314458089519, 23036363772691094229836333217253237353920846158487310676871760642047832279183406136277001090285869741581273000600403111152094511074649824913321839863262906656729226549952126760622546375112636258358119156419276720729160639100672), (12522487755151452321636296110912153312587696989961702566133508697902026427396806962507244285498832447641578601706432705688833318733498102202120773626092164224621750103182935392734181664799052801736670403192038344073075905997843, 16235015760916115964926011096856921961118902124478830012533377841076941038656095966540337882684172623620414493625906317184520934808353542572158474378847050339489727226648236649815074973737903207021589886131177308741763891478875, 23675364518124042074447951143077219100080642308580948340331650285500567862191598861219028945929831519063354710694882580486644431500405814964247718872347363192237308655443507138052713813465575167843055486399098470156176028246725))
+# The MNT twists' G2 generators are NOT here: ark-mnt4-753 / ark-mnt6-753's constants are not recoverable offline, so the
+# product ships none (ptau_new_challenge refuses those curves; the host passes G2Affine::generator() through
+# ptau_new_challenge_with_generators).  The tests bring their own synthetic order-r point.
 
 
 BW6_G1_XY = (0x01075b020ea190c8b277ce98a477beaee6a0cfb7551b27f0ee05c54b85f56fc779017ffac15520ac11dbfcd294c2e746a17a54ce47729b905bd71fa0c9ea097103758f9a280ca27f6750dd0356133e82055928aca6af603f4088f3af66e5b43d,
              0x0058b84e0a6fc574e6fd637b45cc2a420f952589884c9ec61a7348d2a2e573a3265909f1af7e0dbac5b8fa1771b5b806cc685d31717a4c55be3fb90b6fc2cdd49f9df141b3053253b2b08119cad0fb93ad1cb2be0b20d2a1bafc8f2db4e95363)
 BW6_G2_XY = (0x0110133241d9b816c852a82e69d660f9d61053aac5a7115f4c06201013890f6d26b41c5dab3da268734ec3f1f09feb58c5bbcae9ac70e7c7963317a300e1b6bace6948cb3cd208d700e96efbc2ad54b06410cf4fe1bf995ba830c194cd025f1c,
              0x0017c3357761369f8179eb10e4b6d2dc26b7cf9acec2181c81a78e2753ffe3160a1d86c80b95a59c94c97eb733293fef64f293dbd2c712b88906c170ffa823003ea96fcd504affc758aa2d3a3c5a02a591ec0594f9eac689eb70a16728c73b61)
+
+
+def _cofactors():
+    """(G1, G2) cofactors #E/r per curve, from the curve families' parametrisations (ark-*'s COFACTOR constants)."""
+    x = 0x8508c00000000001
+    assert (x ** 4 - x ** 2 + 1) == BLS_R and ((x - 1) ** 2 * BLS_R) // 3 + x == BLS_Q
+    bls = ((x - 1) ** 2 // 3, (x ** 8 - 4 * x ** 7 + 5 * x ** 6 - 4 * x ** 4 + 6 * x ** 3 - 4 * x ** 2 - 4 * x + 13) // 9)
+    # BW6-761 (eprint 2020/351): t = x^5 - 3x^4 + 3x^3 - x + 3 + 13 r, 4q = t^2 + 3y^2; E: y^2 = x^3 - 1 has q + 1 - t points,
+    # the M-twist y^2 = x^3 + 4 has q + 1 - (3y + t)/2
+    import math
+    t = x ** 5 - 3 * x ** 4 + 3 * x ** 3 - x + 3 + 13 * BLS_Q
+    y = math.isqrt((4 * BW6_Q - t * t) // 3)
+    assert t * t + 3 * y * y == 4 * BW6_Q
+    cands = [BW6_Q + 1 - t, BW6_Q + 1 + t, BW6_Q + 1 - (t + 3 * y) // 2, BW6_Q + 1 + (t + 3 * y) // 2,
+             BW6_Q + 1 - (t - 3 * y) // 2, BW6_Q + 1 + (t - 3 * y) // 2]
+    cof = sorted(o // BLS_Q for o in cands if o % BLS_Q == 0)
+    assert len(cof) == 2 and cof[1] - cof[0] == 7
+    bw6 = (cof[1], cof[0])   # ...4876 (G1), ...4869 (G2)
+    # MNT cycle: #E4(Fq4) = r4 = q6, #E6(Fq6) = r6 = q4 (cofactor 1); twists over Fq2 / Fq3 from the traces
+    t4, t6 = MNT_A + 1 - MNT_B, MNT_B + 1 - MNT_A
+    o4 = MNT_A * MNT_A + 1 + (t4 * t4 - 2 * MNT_A)
+    o6 = MNT_B ** 3 + 1 + (t6 ** 3 - 3 * MNT_B * t6)
+    assert o4 % MNT_B == 0 and o6 % MNT_A == 0
+    return {"bls12_377": bls, "bw6": bw6, "mnt4_753": (1, o4 // MNT_B), "mnt6_753": (1, o6 // MNT_A)}
+
+
+COFACTORS = _cofactors()
 
 
 def ec_mul_j0(P, k, p):
@@ -191,7 +217,7 @@ def main():
     out.append("using Mnt4Fr = Mnt6Fq;")
     out.append("using Mnt6Fr = Mnt4Fq;")
 
-    def coeffs(cname, fname, deg, a, b, nr, glv=None, endo=None, glv2=None):
+    def coeffs(cname, fname, deg, a, b, nr, glv=None, endo=None, glv2=None, cofactor=1):
         global _LB
         p, n, R, _LB = fields[fname]
         s = ["struct %s {" % cname]
@@ -252,6 +278,11 @@ def main():
             s.append("  static constexpr uint32_t GLV_BETA[%d] = {%s};" % (n, limbs(beta * R % p, n)))
             s.append("  static constexpr uint32_t GLV_LAMBDA[4] = {%s};" % limbs(lam, 4, 32))
             s.append("  static constexpr uint32_t GLV_M[5] = {%s};" % limbs((1 << 256) // lam, 5, 32))
+        # #E / r (ark-*'s COFACTOR): G::rand and hash_to_g2 clear it (key generation, host side); tests/test_oracle.py
+        # checks cofactor * r * P = O on random curve points
+        cl = max(1, (cofactor.bit_length() + 31) // 32)
+        s.append("  static constexpr int COFACTOR_BITS = %d;" % cofactor.bit_length())
+        s.append("  static constexpr uint32_t COFACTOR[%d] = {%s};" % (cl, limbs(cofactor, cl, 32)))
         s.append("  static constexpr int DEG = %d;" % deg)
         s.append("  static constexpr bool A_IS_ZERO = %s;" % ("true" if not any(a) else "false"))
         # a = A_SMALL * u^A_SHIFT when exactly one coefficient is set and small (doubling uses an addition chain)
@@ -275,7 +306,7 @@ def main():
     # lambda^2 = -x^2 mod r is the eigenvalue of beta^2: the G1 membership test compares (beta^2 x, y) with -[x^2]P
     assert (bls_lambda * bls_lambda + bls_x * bls_x) % BLS_R == 0
     out.append(coeffs("BlsG1Cfg", fq_of("BlsFq"), 1, (0,), (1,), 0, glv=(bls_beta, bls_lambda),
-                      endo=(1, bls_x, bls_beta * bls_beta % BLS_Q, 0)))
+                      endo=(1, bls_x, bls_beta * bls_beta % BLS_Q, 0), cofactor=COFACTORS["bls12_377"][0]))
     # psi(x, y) = (xi^((q-1)/3) conj(x), xi^((q-1)/2) conj(y)), xi = u (D-type twist, b' = b/xi); both constants lie in Fq.
     # Sound because q - x = r (x-1)^2/3 and gcd((x-1)^2/3, #E'(Fq2)/r) = 1 (checked in tests/test_oracle.py).
     def fq2_pow_u(e):   # u^e in Fq[u]/(u^2 + 5)
@@ -288,7 +319,8 @@ def main():
         return r0, r1
     psi_cx, psi_cy = fq2_pow_u((BLS_Q - 1) // 3), fq2_pow_u((BLS_Q - 1) // 2)
     assert psi_cx[1] == 0 and psi_cy[1] == 0
-    out.append(coeffs("BlsG2Cfg", fq_of("BlsFq"), 2, (0, 0), (0, BLS_G2_B1), -5, endo=(2, bls_x, psi_cx[0], psi_cy[0])))
+    out.append(coeffs("BlsG2Cfg", fq_of("BlsFq"), 2, (0, 0), (0, BLS_G2_B1), -5, endo=(2, bls_x, psi_cx[0], psi_cy[0]),
+                      cofactor=COFACTORS["bls12_377"][1]))
     # BW6-761: both groups are j = 0 curves over Fq; one eigenvalue lambda (316 bits), the matching cube root of unity
     # per group (checked against the generators: phi(G) = lambda G)
     gq = 2
@@ -301,12 +333,14 @@ def main():
     bw6_lam = pow(hr, 2 * (BLS_Q - 1) // 3, BLS_Q)
     if bw6_lam.bit_length() > 320:
         bw6_lam = bw6_lam * bw6_lam % BLS_Q
-    out.append(coeffs("Bw6G1Cfg", fq_of("Bw6Fq"), 1, (0,), (BW6_Q - 1,), 0, glv2=(glv_beta_for(BW6_G1_XY, bw6_w, bw6_lam, BW6_Q), bw6_lam, BLS_Q)))
-    out.append(coeffs("Bw6G2Cfg", fq_of("Bw6Fq"), 1, (0,), (4,), 0, glv2=(glv_beta_for(BW6_G2_XY, bw6_w, bw6_lam, BW6_Q), bw6_lam, BLS_Q)))
+    out.append(coeffs("Bw6G1Cfg", fq_of("Bw6Fq"), 1, (0,), (BW6_Q - 1,), 0, glv2=(glv_beta_for(BW6_G1_XY, bw6_w, bw6_lam, BW6_Q), bw6_lam, BLS_Q),
+                      cofactor=COFACTORS["bw6"][0]))
+    out.append(coeffs("Bw6G2Cfg", fq_of("Bw6Fq"), 1, (0,), (4,), 0, glv2=(glv_beta_for(BW6_G2_XY, bw6_w, bw6_lam, BW6_Q), bw6_lam, BLS_Q),
+                      cofactor=COFACTORS["bw6"][1]))
     out.append(coeffs("Mnt4G1Cfg", fq_of("Mnt4Fq"), 1, (2,), (MNT4_B1,), 0))
-    out.append(coeffs("Mnt4G2Cfg", fq_of("Mnt4Fq"), 2, (26, 0), (0, MNT4_B1 * 13 % MNT_A), 13))
+    out.append(coeffs("Mnt4G2Cfg", fq_of("Mnt4Fq"), 2, (26, 0), (0, MNT4_B1 * 13 % MNT_A), 13, cofactor=COFACTORS["mnt4_753"][1]))
     out.append(coeffs("Mnt6G1Cfg", fq_of("Mnt6Fq"), 1, (11,), (MNT6_B1,), 0))
-    out.append(coeffs("Mnt6G2Cfg", fq_of("Mnt6Fq"), 3, (0, 0, 11), (MNT6_B1 * 11 % MNT_B, 0, 0), 11))
+    out.append(coeffs("Mnt6G2Cfg", fq_of("Mnt6Fq"), 3, (0, 0, 11), (MNT6_B1 * 11 % MNT_B, 0, 0), 11, cofactor=COFACTORS["mnt6_753"][1]))
     # ---- pairing tail (host): Fq^k = Fq[w]/(w^k - NU), untwist sign, Frobenius constant, hard exponent
     def cyclo(k, q):
         return {4: q * q + 1, 6: q * q - q + 1, 12: q ** 4 - q * q + 1}[k]
@@ -371,9 +405,7 @@ def main():
     out.append("  " + gen_bytes("BW6_G1", ser(BW6_Q, *BW6_G1)))
     out.append("  " + gen_bytes("BW6_G2", ser(BW6_Q, *BW6_G2)))
     out.append("  " + gen_bytes("MNT4_G1", ser(MNT_A, *MNT4_G1)))
-    out.append("  " + gen_bytes("MNT4_G2", ser(MNT_A, *MNT4_G2_GEN)))
     out.append("  " + gen_bytes("MNT6_G1", ser(MNT_B, *MNT6_G1)))
-    out.append("  " + gen_bytes("MNT6_G2", ser(MNT_B, *MNT6_G2_GEN)))
     out.append("};")
     out.append("}  // namespace ptau")
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "curve_constants.inc")

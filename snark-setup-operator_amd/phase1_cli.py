@@ -48,6 +48,12 @@ class BatchExpMode(enum.IntEnum):
     BatchInversion = 2
 
 
+# include/ptau.h PTAU_BATCH_EXP_INPUT_IN_SUBGROUP: OR into a BatchExpMode when the caller KNOWS every challenge element is
+# in the prime-order subgroup (the challenge came out of a verifier that ran the subgroup checks): enables the
+# endomorphism-accelerated multiplication without a membership pass.  Not a reference mode: an integration choice.
+INPUT_IN_SUBGROUP = 0x100
+
+
 class SubgroupCheckMode(enum.IntEnum):
     Auto = 0
     Direct = 1
@@ -164,7 +170,7 @@ def contribute(challenge_filename, challenge_hash_filename, response_filename, r
 
 
 def computation(challenge: bytes, parameters: Phase1Parameters, key: PrivateKey, check_input=CheckForCorrectness.No,
-                device: int = 0) -> bytes:
+                batch_exp_mode=BatchExpMode.Auto, device: int = 0) -> bytes:
     """Phase1::computation on in-memory buffers: returns a contribution_size buffer whose element
     region is filled (hash header and public-key tail left zero)."""
     L = _lib.load_library()
@@ -173,13 +179,13 @@ def computation(challenge: bytes, parameters: Phase1Parameters, key: PrivateKey,
     eb = _lib.errbuf()
     rc = L.ptau_phase1_computation(ctypes.byref(parameters._c()), challenge, len(challenge), out, len(out),
                                    _lib.limbs(key.tau, nl), _lib.limbs(key.alpha, nl), _lib.limbs(key.beta, nl),
-                                   int(check_input), device, eb, len(eb))
+                                   int(check_input), int(batch_exp_mode), device, eb, len(eb))
     _lib.check(rc, eb)
     return out.raw
 
 
 def apply_powers(curve, group, data: bytes, n, start, tau, coeff=None, compressed_in=False, compressed_out=True,
-                 check_input=CheckForCorrectness.No, device=0) -> bytes:
+                 check_input=CheckForCorrectness.No, batch_exp_mode=BatchExpMode.Auto, device=0) -> bytes:
     """setup-utils apply_powers / batch_exp on one vector (host buffers)."""
     L = _lib.load_library()
     c = curve_from_str(curve) if isinstance(curve, str) else int(curve)
@@ -187,7 +193,8 @@ def apply_powers(curve, group, data: bytes, n, start, tau, coeff=None, compresse
     out = ctypes.create_string_buffer(max(1, n * L.ptau_point_size(c, group, int(compressed_out))))
     eb = _lib.errbuf()
     rc = L.ptau_apply_powers(c, group, data, int(compressed_in), out, int(compressed_out), n, start, _lib.limbs(tau, nl),
-                             None if coeff is None else _lib.limbs(coeff, nl), int(check_input), device, eb, len(eb))
+                             None if coeff is None else _lib.limbs(coeff, nl), int(check_input), int(batch_exp_mode), device,
+                             eb, len(eb))
     _lib.check(rc, eb)
     return out.raw[:n * L.ptau_point_size(c, group, int(compressed_out))]
 
@@ -213,15 +220,16 @@ def subgroup_check(curve, group, data: bytes, n, compressed_in=False, device=0) 
 
 def verification_and_decompress(challenge: bytes, response: bytes, parameters: Phase1Parameters,
                                 check_input=CheckForCorrectness.No, check_output=CheckForCorrectness.OnlyNonZero,
-                                subgroup_check_mode=SubgroupCheckMode.Auto, ratio_check=False, tau_g2_check: bytes = None,
-                                device=0) -> bytes:
-    """Element part of Phase1::verification + Phase1::decompress on in-memory buffers; returns new_challenge."""
+                                subgroup_check_mode=SubgroupCheckMode.Auto, ratio_check=False, verify_pok=False,
+                                g2_s: bytes = None, tau_g2_check: bytes = None, device=0) -> bytes:
+    """Phase1::verification + Phase1::decompress on in-memory buffers; returns new_challenge.  verify_pok=False runs the
+    element checks only (the parity tests' synthetic public keys carry no proofs of knowledge)."""
     L = _lib.load_library()
     out = ctypes.create_string_buffer(parameters.accumulator_size)
     eb = _lib.errbuf()
     rc = L.ptau_verify_chunk(ctypes.byref(parameters._c()), challenge, len(challenge), response, len(response), out, len(out),
                              int(check_input), int(check_output), int(subgroup_check_mode), int(bool(ratio_check)),
-                             tau_g2_check, device, eb, len(eb))
+                             int(bool(verify_pok)), g2_s, tau_g2_check, device, eb, len(eb))
     _lib.check(rc, eb)
     return out.raw
 
@@ -229,15 +237,61 @@ def verification_and_decompress(challenge: bytes, response: bytes, parameters: P
 def transform_pok_and_correctness(challenge_filename, challenge_hash_filename, check_input_correctness, response_filename,
                                   response_hash_filename, check_output_correctness, new_challenge_filename,
                                   new_challenge_hash_filename, subgroup_check_mode, ratio_check,
-                                  parameters: Phase1Parameters, tau_g2_check: bytes = None, device: int = 0):
-    """phase1_cli::transform_pok_and_correctness (contribute.rs:968-986), same argument order."""
+                                  parameters: Phase1Parameters, g2_s: bytes = None, device: int = 0):
+    """phase1_cli::transform_pok_and_correctness (contribute.rs:968-986), the reference's eleven arguments in its order.
+    Proofs of knowledge are always checked; g2_s=None lets the library derive the compute_g2_s points itself."""
     L = _lib.load_library()
     eb = _lib.errbuf()
     rc = L.ptau_transform_pok_and_correctness_file(
         ctypes.byref(parameters._c()), os.fsencode(challenge_filename), os.fsencode(challenge_hash_filename),
         int(check_input_correctness), os.fsencode(response_filename), os.fsencode(response_hash_filename),
         int(check_output_correctness), os.fsencode(new_challenge_filename), os.fsencode(new_challenge_hash_filename),
-        int(subgroup_check_mode), int(bool(ratio_check)), tau_g2_check, device, eb, len(eb))
+        int(subgroup_check_mode), int(bool(ratio_check)), g2_s, device, eb, len(eb))
+    _lib.check(rc, eb)
+
+
+def derive_rng_words(seed: bytes, n_words: int, word_offset: int = 0):
+    """setup_utils::derive_rng_from_seed (contribute.rs:783-789): the ChaCha20Rng word stream of the first 32 seed bytes."""
+    L = _lib.load_library()
+    out = (ctypes.c_uint32 * n_words)()
+    rc = L.ptau_chacha20_rng_words(seed[:32], word_offset, out, n_words)
+    if rc:
+        raise _lib.PtauError(rc, "ptau_chacha20_rng_words")
+    return list(out)
+
+
+def key_generation(curve, seed: bytes, digest: bytes) -> PrivateKey:
+    """Phase1::key_generation(derive_rng_from_seed(seed), digest) -> PrivateKey (with the serialized PublicKey)."""
+    L = _lib.load_library()
+    c = curve_from_str(curve) if isinstance(curve, str) else int(curve)
+    nl = L.ptau_fr_limbs(c)
+    t, a, b = [(ctypes.c_uint64 * nl)() for _ in range(3)]
+    pk = ctypes.create_string_buffer(6 * L.ptau_point_size(c, 1, 0) + 3 * L.ptau_point_size(c, 2, 0))
+    eb = _lib.errbuf()
+    _lib.check(L.ptau_key_generation(c, seed, len(seed), digest, t, a, b, pk, len(pk), eb, len(eb)), eb)
+    val = lambda arr: sum(int(v) << (64 * k) for k, v in enumerate(arr))
+    return PrivateKey(val(t), val(a), val(b), pk.raw)
+
+
+def compute_g2_s(curve, digest: bytes, public_key: bytes) -> bytes:
+    """The three setup_utils::compute_g2_s points of a serialized PublicKey (uncompressed G2 x 3)."""
+    L = _lib.load_library()
+    c = curve_from_str(curve) if isinstance(curve, str) else int(curve)
+    out = ctypes.create_string_buffer(3 * L.ptau_point_size(c, 2, 0))
+    eb = _lib.errbuf()
+    _lib.check(L.ptau_compute_g2_s(c, digest, public_key, len(public_key), out, eb, len(eb)), eb)
+    return out.raw
+
+
+def contribute_seeded(challenge_filename, challenge_hash_filename, response_filename, response_hash_filename,
+                      check_input_correctness, batch_exp_mode, parameters: Phase1Parameters, seed: bytes, device: int = 0):
+    """phase1_cli::contribute with rng = derive_rng_from_seed(seed) (contribute.rs:783-789, 811-823)."""
+    L = _lib.load_library()
+    eb = _lib.errbuf()
+    rc = L.ptau_contribute_file_seeded(ctypes.byref(parameters._c()), os.fsencode(challenge_filename),
+                                       os.fsencode(challenge_hash_filename), os.fsencode(response_filename),
+                                       os.fsencode(response_hash_filename), seed, len(seed), int(check_input_correctness),
+                                       int(batch_exp_mode), device, eb, len(eb))
     _lib.check(rc, eb)
 
 
@@ -307,6 +361,26 @@ def new_challenge(challenge_filename, challenge_hash_filename, parameters: Phase
     eb = _lib.errbuf()
     _lib.check(L.ptau_new_challenge_file(ctypes.byref(parameters._c()), os.fsencode(challenge_filename),
                                          os.fsencode(challenge_hash_filename), eb, len(eb)), eb)
+
+
+def generator(curve, group) -> bytes:
+    """Built-in group generator, uncompressed (PtauError -10 for the G2 of MNT4-753 / MNT6-753)."""
+    L = _lib.load_library()
+    c = curve_from_str(curve) if isinstance(curve, str) else int(curve)
+    out = ctypes.create_string_buffer(L.ptau_point_size(c, group, 0))
+    eb = _lib.errbuf()
+    _lib.check(L.ptau_generator(c, group, out, len(out), eb, len(eb)), eb)
+    return out.raw
+
+
+def initialization_with_generators(parameters: Phase1Parameters, g1_generator: bytes, g2_generator: bytes) -> bytes:
+    """Phase1::initialization with caller-supplied generators (uncompressed): the MNT curves' path."""
+    L = _lib.load_library()
+    out = ctypes.create_string_buffer(parameters.accumulator_size)
+    eb = _lib.errbuf()
+    _lib.check(L.ptau_new_challenge_with_generators(ctypes.byref(parameters._c()), g1_generator, g2_generator, out, len(out),
+                                                    eb, len(eb)), eb)
+    return out.raw
 
 
 def initialization(parameters: Phase1Parameters) -> bytes:

@@ -59,3 +59,16 @@ def load_golden(curve):
 @pytest.fixture(scope="session")
 def golden():
     return {c: load_golden(c) for c in CURVE_NAMES}
+
+
+def initial_challenge(pkg, name, prm):
+    """Phase1::initialization through the C ABI.  The product holds no G2 generator for MNT4-753 / MNT6-753 (arkworks'
+    constants are not recoverable offline): there the oracle's synthetic order-r point goes through the
+    caller-supplied-generators form, as the Rust host would pass G2Affine::generator()."""
+    if not name.startswith("mnt"):
+        return pkg.phase1_cli.initialization(prm)
+    from oracle.pyref import serde
+    from oracle.pyref.curves import CURVES
+    from oracle.pyref.ec import Group
+    G1, G2 = Group(CURVES[name], 1), Group(CURVES[name], 2)
+    return pkg.phase1_cli.initialization_with_generators(prm, serde.write_point(G1, G1.gen, False), serde.write_point(G2, G2.gen, False))

@@ -4,7 +4,7 @@ import random
 
 import pytest
 
-from conftest import CURVE_NAMES
+from conftest import CURVE_NAMES, initial_challenge
 from oracle.pyref import phase1 as P, serde
 from oracle.pyref.curves import CURVES
 from oracle.pyref.ec import Group
@@ -106,21 +106,66 @@ def test_subgroup_check_api(name, pkg):
 
 
 def test_transform_pok_and_correctness_files(pkg, golden, tmp_path):
+    """The ONE file-level call named after phase1_cli::transform_pok_and_correctness checks the proofs of knowledge and the
+    chunk-0 before/after ratios itself (Phase1::verification steps 1-2), not only the elements."""
     name = "bls12_377"
     doc = golden[name]
     ch = doc["chunks"][0]
     prm = _params(pkg, name, doc, 0)
+    p = P.Params(CURVES[name], P.CHUNKED, 0, doc["chunk_size"], doc["power"], doc["batch_size"])
+    challenge, response = bytes.fromhex(ch["challenge"]), bytes.fromhex(ch["response"])
+    g2_s = P.synthetic_g2_s(p, P.calculate_hash(challenge))   # the golden key's base points, as the Rust host would pass compute_g2_s
     f = {k: str(tmp_path / k) for k in ("challenge", "challenge.hash", "response", "response.hash", "new_challenge", "new_challenge.hash")}
-    open(f["challenge"], "wb").write(bytes.fromhex(ch["challenge"]))
-    open(f["response"], "wb").write(bytes.fromhex(ch["response"]))
+    open(f["challenge"], "wb").write(challenge)
+    open(f["response"], "wb").write(response)
     pkg.transform_pok_and_correctness(f["challenge"], f["challenge.hash"], pkg.CheckForCorrectness.No, f["response"],
                                       f["response.hash"], pkg.CheckForCorrectness.OnlyNonZero, f["new_challenge"],
-                                      f["new_challenge.hash"], pkg.SubgroupCheckMode.Auto, False, prm)
+                                      f["new_challenge.hash"], pkg.SubgroupCheckMode.Auto, False, prm, g2_s=g2_s)
     assert open(f["challenge.hash"], "rb").read().hex() == ch["challenge_hash"]
     assert open(f["response.hash"], "rb").read().hex() == ch["response_hash"]
     assert open(f["new_challenge.hash"], "rb").read().hex() == ch["new_challenge_hash"]
     nc = open(f["new_challenge"], "rb").read()
     assert pkg.calculate_hash(nc).hex() == ch["new_challenge_hash"]
+    # forged proof of knowledge: the elements are those of an honest response, the public key proves ANOTHER tau
+    tau, alpha, beta = (int(ch[k], 16) for k in ("tau", "alpha", "beta"))
+    other_pk = P.synthetic_public_key(p, (tau + 1) % CURVES[name].r, alpha, beta, P.calculate_hash(challenge))
+    forged = response[:-len(other_pk)] + other_pk
+    for k, (g, code) in enumerate(((g2_s, -6), (None, -6))):   # caller-supplied and library-derived g2_s both reject
+        fr, fn = str(tmp_path / ("forged%d" % k)), str(tmp_path / ("forged%d.nc" % k))
+        open(fr, "wb").write(forged)
+        with pytest.raises(pkg.PtauError) as e:
+            pkg.transform_pok_and_correctness(f["challenge"], fr + ".ch", pkg.CheckForCorrectness.No, fr, fr + ".h",
+                                              pkg.CheckForCorrectness.OnlyNonZero, fn, fn + ".h", pkg.SubgroupCheckMode.Auto,
+                                              False, prm, g2_s=g)
+        assert e.value.code == code
+    # the golden (synthetic) key is NOT one the library's own compute_g2_s derivation accepts: g2_s = None rejects it too
+    fn = str(tmp_path / "derived.nc")
+    with pytest.raises(pkg.PtauError) as e:
+        pkg.transform_pok_and_correctness(f["challenge"], fn + ".ch", pkg.CheckForCorrectness.No, f["response"], fn + ".rh",
+                                          pkg.CheckForCorrectness.OnlyNonZero, fn, fn + ".h", pkg.SubgroupCheckMode.Auto, False, prm)
+    assert e.value.code == -6
+    # check_input is honoured (--force-correctness-checks): a challenge with a point at infinity / off the subgroup is refused
+    G1 = Group(CURVES[name], 1)
+    bad_ch = bytearray(challenge)
+    bad_ch[64 + 96:64 + 192] = serde.write_point(G1, None, False)
+    fc, fn = str(tmp_path / "bad.challenge"), str(tmp_path / "bad.nc")
+    open(fc, "wb").write(bytes(bad_ch))
+    bad_resp = pkg.calculate_hash(bytes(bad_ch)) + response[64:]
+    fr = str(tmp_path / "bad.response")
+    open(fr, "wb").write(bad_resp)
+    with pytest.raises(pkg.PtauError) as e:
+        pkg.transform_pok_and_correctness(fc, fc + ".h", pkg.CheckForCorrectness.Full, fr, fr + ".h",
+                                          pkg.CheckForCorrectness.OnlyNonZero, fn, fn + ".h", pkg.SubgroupCheckMode.Auto, False, prm, g2_s=g2_s)
+    assert e.value.code == -4
+    bad_ch[64 + 96:64 + 192] = serde.write_point(G1, _off_subgroup_point(G1, random.Random(4)), False)
+    open(fc, "wb").write(bytes(bad_ch))
+    open(fr, "wb").write(pkg.calculate_hash(bytes(bad_ch)) + response[64:])
+    for chk, code in ((pkg.CheckForCorrectness.OnlyInGroup, -5), (pkg.CheckForCorrectness.Full, -5)):
+        fn = str(tmp_path / ("bad%d.nc" % int(chk)))
+        with pytest.raises(pkg.PtauError) as e:
+            pkg.transform_pok_and_correctness(fc, fc + ".h2", chk, fr, fr + ".h2", pkg.CheckForCorrectness.OnlyNonZero, fn, fn + ".h",
+                                              pkg.SubgroupCheckMode.Auto, False, prm, g2_s=g2_s)
+        assert e.value.code == code
 
 
 def test_contribute_verify_round_trip_2pow12(pkg, cref):
@@ -207,9 +252,9 @@ def test_verify_with_ratio_check(name, pkg, golden):
     off_g2 = {nm: o for (nm, g, o, cnt) in p0.layout(False)[0]}["tau_g2"]
     tau_g2_check = nc0[off_g2:off_g2 + 2 * G2.uncomp_size]
     chal1, resp1 = bytes.fromhex(ch1["challenge"]), bytes.fromhex(ch1["response"])
-    with pytest.raises(pkg.PtauError) as e:
-        pkg.phase1_cli.verification_and_decompress(chal1, resp1, prm1, ratio_check=True)
-    assert e.value.code == -1
+    # without tau_g2_check an honest tauG1-only chunk still verifies (its own files hold no G2 pair of ratio tau: the
+    # power ratios of such a chunk are left to transform_ratios on the combined accumulator, control.rs:587-591)
+    assert pkg.phase1_cli.verification_and_decompress(chal1, resp1, prm1, ratio_check=True)[64:] == P.new_challenge_from_response(p1, resp1)[64:]
     nc1 = pkg.phase1_cli.verification_and_decompress(chal1, resp1, prm1, ratio_check=True, tau_g2_check=tau_g2_check)
     assert pkg.calculate_hash(nc1).hex() == ch1["new_challenge_hash"]
     assert P.verify_chunk_ratios(p1, resp1, tau_g2_check=tuple(serde.read_batch(G2, tau_g2_check, False)), rng=random.Random(2))
@@ -247,7 +292,7 @@ def test_round_combine_and_transform_ratios(name, pkg):
     responses, oparams = [], []
     for i in range(n_chunks):
         prm = pkg.Phase1Parameters.new_chunk(name, 0, i, cs, 0, power, cs)
-        ch = pkg.phase1_cli.initialization(prm)
+        ch = initial_challenge(pkg, name, prm)
         key = pkg.PrivateKey(*key_scalars, bytes(prm.public_key_size))
         resp = bytearray(pkg.phase1_cli.computation(ch, prm, key))
         resp[:64] = pkg.calculate_hash(ch)
@@ -268,7 +313,7 @@ def test_round_combine_and_transform_ratios(name, pkg):
     # chunks contributed with DIFFERENT keys do not combine into a valid accumulator
     prm1 = pkg.Phase1Parameters.new_chunk(name, 0, 1, cs, 0, power, cs)
     other = pkg.PrivateKey(key_scalars[0] + 1, key_scalars[1], key_scalars[2], bytes(prm1.public_key_size))
-    r1 = bytearray(pkg.phase1_cli.computation(pkg.phase1_cli.initialization(prm1), prm1, other))
+    r1 = bytearray(pkg.phase1_cli.computation(initial_challenge(pkg, name, prm1), prm1, other))
     mixed = pkg.combine([responses[0], bytes(r1)] + responses[2:], cs, full)
     with pytest.raises(pkg.PtauError) as e:
         pkg.transform_ratios(mixed, pkg.CheckForCorrectness.No, full)
@@ -277,17 +322,19 @@ def test_round_combine_and_transform_ratios(name, pkg):
 
 def test_e2e_phase1_config1_files(pkg, cref, tmp_path):
     """BASELINE configs[0] — e2e/e2ephase1.sh BLS12-377 --powers 12 --chunk-size 10 — through the FILE-level entry points
-    the operator calls: new_challenge, two rounds of contribute -> transform_pok_and_correctness on all 8 chunks
-    (4 full + 4 tauG1-only), then combine + transform_ratios on the last responses.  Hash chain and `.hash` side files
-    checked at every step; every response is bit-exact vs the C oracle's Phase1::computation."""
+    the operator calls, with the reference's own argument lists: new_challenge, two rounds of contribute ->
+    transform_pok_and_correctness (ratio_check = true, the operator default) on all 8 chunks (4 full + 4 tauG1-only), then
+    combine + transform_ratios on the last responses.  Round 0 contributes from a SEED (derive_rng_from_seed +
+    Phase1::key_generation inside the library), round 1 with a key pair made by ptau_key_generation on the host side; the
+    verifier derives compute_g2_s itself and checks every proof of knowledge.  Hash chain and `.hash` side files checked at
+    every step; every response is bit-exact vs the C oracle's Phase1::computation."""
     name, power, cs = "bls12_377", 12, 1 << 10
-    rng = random.Random(2024)
     full = pkg.Phase1Parameters.new_full(name, 0, power, cs)
     n_chunks = -(-full.powers_g1_length // cs)
     assert n_chunks == 8
-    keys = [[rng.randrange(1, CURVES[name].r) for _ in range(3)] for _ in range(2)]
+    seeds = [bytes([7 + rnd]) * 64 for rnd in range(2)]
     final_responses = []
-    tau_g2_check = [None, None]
+    taus = [None, None]
     for i in range(n_chunks):
         prm = pkg.Phase1Parameters.new_chunk(name, 0, i, cs, 0, power, cs)
         f = lambda s: str(tmp_path / ("chunk%d_%s" % (i, s)))
@@ -296,10 +343,15 @@ def test_e2e_phase1_config1_files(pkg, cref, tmp_path):
         assert len(ch) == prm.accumulator_size and ch[:64].hex().startswith("786a02f742015903c6c6fd852552d272")
         assert open(f("challenge0.hash"), "rb").read() == pkg.calculate_hash(ch)
         for rnd in range(2):
-            key = pkg.PrivateKey(*keys[rnd], (bytes(range(256)) * 12)[:prm.public_key_size])
             c, r, nc = f("challenge%d" % rnd), f("response%d" % rnd), f("challenge%d" % (rnd + 1))
-            pkg.contribute(c, c + ".h", r, r + ".hash", pkg.CheckForCorrectness.No, pkg.BatchExpMode.Auto, prm, key)
-            chal, resp = open(c, "rb").read(), open(r, "rb").read()
+            chal = open(c, "rb").read()
+            key = pkg.phase1_cli.key_generation(name, seeds[rnd], pkg.calculate_hash(chal))
+            taus[rnd] = key.tau
+            if rnd == 0:
+                pkg.phase1_cli.contribute_seeded(c, c + ".h", r, r + ".hash", pkg.CheckForCorrectness.No, pkg.BatchExpMode.Auto, prm, seeds[rnd])
+            else:
+                pkg.contribute(c, c + ".h", r, r + ".hash", pkg.CheckForCorrectness.No, pkg.BatchExpMode.Auto, prm, key)
+            resp = open(r, "rb").read()
             assert resp[:64] == pkg.calculate_hash(chal) == open(c + ".h", "rb").read()
             assert open(r + ".hash", "rb").read() == pkg.calculate_hash(resp)
             assert resp[-prm.public_key_size:] == key.public_key
@@ -309,26 +361,55 @@ def test_e2e_phase1_config1_files(pkg, cref, tmp_path):
             with pytest.raises(pkg.PtauError) as e:      # create_new semantics: the stale response is never overwritten
                 pkg.contribute(c, c + ".h", r, r + ".hash", pkg.CheckForCorrectness.No, pkg.BatchExpMode.Auto, prm, key)
             assert e.value.code == -9
-            kw = {}
-            if prm.other_chunk_size == 0:
-                kw["tau_g2_check"] = tau_g2_check[rnd]
             pkg.transform_pok_and_correctness(c, c + ".vh", pkg.CheckForCorrectness.No, r, r + ".vh",
                                               pkg.CheckForCorrectness.OnlyNonZero, nc, nc + ".hash", pkg.SubgroupCheckMode.Auto,
-                                              True, prm, **kw)
+                                              True, prm)
             new_ch = open(nc, "rb").read()
             assert new_ch[:64] == pkg.calculate_hash(resp) == open(r + ".vh", "rb").read()
             assert open(nc + ".hash", "rb").read() == pkg.calculate_hash(new_ch)
-            if i == 0:    # (tauG2[0], tauG2[1]) of this contribution, for the tauG1-only chunks
-                off = 64 + prm.g1_chunk_size * 96
-                tau_g2_check[rnd] = new_ch[off:off + 2 * 192]
         final_responses.append(open(f("response1"), "rb").read())
     combined = pkg.combine(final_responses, cs, full)
     assert len(combined) == full.accumulator_size
     pkg.transform_ratios(combined, pkg.CheckForCorrectness.Full, full)
     # the combined accumulator is [ (tau0*tau1)^i G ]: element 1 of tauG1 is (tau0*tau1) G
-    t = keys[0][0] * keys[1][0] % CURVES[name].r
+    t = taus[0] * taus[1] % CURVES[name].r
     G1 = Group(CURVES[name], 1)
     assert combined[64 + 96:64 + 192] == serde.write_point(G1, G1.mul(G1.gen, t), False)
+
+
+@pytest.mark.parametrize("name,group", [("bls12_377", 1), ("bls12_377", 2), ("bw6", 1), ("bw6", 2)])
+def test_batch_exp_exact_on_any_curve_point(name, group, pkg, cref):
+    """arkworks' batch_exp returns [k]P for ANY curve point, and contribute's default is CheckForCorrectness::No
+    (contribute.rs:816-819): with unchecked input the update must be exact on points OUTSIDE the prime-order subgroup too,
+    where the endomorphisms are not [lambda] / [x].  Auto and Direct give the oracle's bytes on a vector that mixes
+    subgroup points, cofactor-only points and mixed points; the endomorphism path (membership established by check_input,
+    or asserted by the caller) gives the same bytes on subgroup points."""
+    c = CURVES[name]
+    G = Group(c, group)
+    rng = random.Random(31 + group)
+    good = [G.mul(G.gen, rng.randrange(1, c.r)) for _ in range(5)]
+    off = [_off_subgroup_point(G, rng) for _ in range(3)]
+    cof_only = G.mul(off[0], c.r)                  # order divides the cofactor
+    assert cof_only is not None and not G.in_subgroup(off[1])
+    pts = [good[0], off[0], good[1], cof_only, off[1], good[2], G.add(good[3], cof_only), off[2], None]
+    n = len(pts)
+    data = serde.write_batch(G, pts, False)
+    tau, coeff = rng.randrange(c.r), rng.randrange(1, c.r)
+    for cout in (True, False):
+        exp = cref.apply_powers(name, group, data, n, 5, tau, coeff, False, cout)
+        for mode in (pkg.BatchExpMode.Auto, pkg.BatchExpMode.Direct, pkg.BatchExpMode.BatchInversion):
+            got = pkg.phase1_cli.apply_powers(name, group, data, n, 5, tau, coeff, False, cout, batch_exp_mode=mode)
+            assert got == exp, (name, group, mode, cout)
+    # subgroup points: every path agrees with the oracle, including the asserted-membership one
+    gdata = serde.write_batch(G, good, False)
+    exp = cref.apply_powers(name, group, gdata, 5, 9, tau, None, False, True)
+    for mode, chk in ((pkg.BatchExpMode.Auto, pkg.CheckForCorrectness.No), (pkg.BatchExpMode.Auto, pkg.CheckForCorrectness.Full),
+                      (int(pkg.BatchExpMode.Auto) | pkg.phase1_cli.INPUT_IN_SUBGROUP, pkg.CheckForCorrectness.No),
+                      (pkg.BatchExpMode.Direct, pkg.CheckForCorrectness.Full)):
+        assert pkg.phase1_cli.apply_powers(name, group, gdata, 5, 9, tau, None, False, True, check_input=chk, batch_exp_mode=mode) == exp
+    with pytest.raises(pkg.PtauError) as e:
+        pkg.phase1_cli.apply_powers(name, group, gdata, 5, 9, tau, batch_exp_mode=7)
+    assert e.value.code == -1
 
 
 @pytest.mark.parametrize("name,group", [("bls12_377", 1), ("bls12_377", 2), ("bw6", 1)])

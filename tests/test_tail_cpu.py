@@ -7,13 +7,37 @@ from oracle.pyref import phase1 as P
 from oracle.pyref.curves import CURVES
 
 
+def _oracle_generators(c):
+    from oracle.pyref import serde
+    from oracle.pyref.ec import Group
+    G1, G2 = Group(c, 1), Group(c, 2)
+    return serde.write_point(G1, G1.gen, False), serde.write_point(G2, G2.gen, False)
+
+
 @pytest.mark.parametrize("name", CURVE_NAMES)
 def test_new_challenge_matches_oracle(name, pkg, tmp_path):
+    """Phase1::initialization.  BLS12-377 / BW6-761: built-in generators.  MNT4 / MNT6: the product holds no G2 generator
+    (arkworks' constants are not recoverable offline) — the built-in form refuses, the caller-supplied form is exact."""
     c = CURVES[name]
+    g1b, g2b = _oracle_generators(c)
+    mnt = name.startswith("mnt")
     for idx in (0, 1):
         prm = pkg.Phase1Parameters.new_chunk(name, 0, idx, 4, 0, 2, 4)
         exp = P.initialization(P.Params(c, P.CHUNKED, idx, 4, 2, 4))
-        assert pkg.phase1_cli.initialization(prm) == exp
+        assert pkg.phase1_cli.initialization_with_generators(prm, g1b, g2b) == exp
+        if mnt:
+            with pytest.raises(pkg.PtauError) as e:
+                pkg.phase1_cli.initialization(prm)
+            assert e.value.code == -10
+        else:
+            assert pkg.phase1_cli.initialization(prm) == exp
+    assert pkg.phase1_cli.generator(name, 1) == g1b
+    if mnt:
+        with pytest.raises(pkg.PtauError) as e:
+            pkg.phase1_cli.generator(name, 2)
+        assert e.value.code == -10
+        return
+    assert pkg.phase1_cli.generator(name, 2) == g2b
     f, fh = str(tmp_path / "challenge"), str(tmp_path / "challenge.hash")
     prm = pkg.Phase1Parameters.new_full(name, 0, 2, 4)
     pkg.new_challenge(f, fh, prm)
