@@ -193,9 +193,9 @@ def test_full_size_bls12_377_tau_g1(pkg, cref):
 
 
 @pytest.mark.parametrize("name,group,log2n", [("bls12_377", 1, 20), ("bls12_377", 2, 20), ("bw6", 1, 18), ("bw6", 2, 18),
-                                              ("mnt4_753", 1, 16), ("mnt4_753", 2, 14), ("mnt6_753", 1, 16), ("mnt6_753", 2, 13)])
+                                              ("mnt4_753", 1, 16), ("mnt4_753", 2, 16), ("mnt6_753", 1, 16), ("mnt6_753", 2, 16)])
 def test_full_size_round_trip(name, group, log2n, pkg, cref):
-    """BASELINE-size vectors (configs 2-4: 2^20 BLS12-377, 2^18 BW6-761, 2^16 MNT G1) through size-independent properties:
+    """BASELINE-size vectors (configs 2-4: 2^20 BLS12-377, 2^18 BW6-761, 2^16 MNT4 / MNT6, G1 and G2) through size-independent properties:
     a tau-update followed by the tau^-1-update at the same offset is the identity on the bytes, compressed output is the
     uncompressed output with y dropped (same x bytes, flags moved), and the first / last 128 elements are bit-exact
     vs the C oracle."""
@@ -213,6 +213,9 @@ def test_full_size_round_trip(name, group, log2n, pkg, cref):
     back = pkg.phase1_cli.apply_powers(name, group, w, n, start, pow(tau, -1, c.r), None, False, False)
     assert back == v
     wc = pkg.phase1_cli.apply_powers(name, group, v, n, start, tau, None, False, True)
+    if name in ("bls12_377", "bw6"):   # the endomorphism path (membership asserted: v is [s^i G]) writes the same bytes as the exact one
+        endo = int(pkg.BatchExpMode.Auto) | pkg.phase1_cli.INPUT_IN_SUBGROUP
+        assert pkg.calculate_hash(pkg.phase1_cli.apply_powers(name, group, v, n, start, tau, None, False, True, batch_exp_mode=endo)) == pkg.calculate_hash(wc)
     fb = c.fq_bytes
     for i in (0, 1, n // 2, n - 1):                      # compressed = x bytes of the uncompressed form, sign flag from y
         xu, xc = bytearray(w[i * u:i * u + cs]), bytearray(wc[i * cs:(i + 1) * cs])
@@ -243,3 +246,90 @@ def test_update_passes_points_at_infinity_through(name, group, pkg, cref):
         assert got == cref.apply_powers(name, group, data, 10, 5, tau, None, False, cout)
     inf_c = serde.write_point(G, None, True)
     assert got is not None and pkg.phase1_cli.apply_powers(name, group, data, 10, 5, tau, None, False, True)[:G.comp_size] == inf_c
+
+
+@pytest.mark.parametrize("name", ["bls12_377", "bw6"])
+def test_full_mode_contribute_and_verify(name, pkg, tmp_path):
+    """ContributionMode::Full (beacon application and the final check of verify_transcript: /root/reference/src/bin/
+    verify_transcript.rs:675-696, 745-776, src/bin/control.rs:781-808): one accumulator holds every power — 2^(p+1) - 1
+    tauG1 elements, 2^p of the others.  Phase1::computation, transform_pok_and_correctness (file level, proofs of knowledge
+    and the chunk-0-style before/after checks, ratio check) and the result's independence of batch_size, against the
+    Python oracle."""
+    from oracle.pyref import keygen as K
+    c = CURVES[name]
+    power = 3
+    p = P.Params(c, P.FULL, 0, 1 << power, power, 4)
+    prm = pkg.Phase1Parameters.new_full(name, 0, power, 4)
+    assert prm.accumulator_size == p.accumulator_size and prm.g1_chunk_size == (2 << power) - 1 and prm.other_chunk_size == 1 << power
+    ch0 = P.initialization(p)
+    assert pkg.phase1_cli.initialization(prm) == ch0
+    f = lambda s: str(tmp_path / s)
+    open(f("c0"), "wb").write(ch0)
+    seed = bytes(range(100, 164))
+    pkg.phase1_cli.contribute_seeded(f("c0"), f("c0.h"), f("r0"), f("r0.h"), pkg.CheckForCorrectness.Full, pkg.BatchExpMode.Auto, prm, seed)
+    tau, alpha, beta, pk, _ = K.key_generation(c, seed, P.calculate_hash(ch0))
+    resp = open(f("r0"), "rb").read()
+    assert resp == P.calculate_hash(ch0) + P.computation(p, ch0, tau, alpha, beta) + pk
+    # batch_size is a memory knob of the reference (it iterates batch_size slices): the bytes do not depend on it
+    for bs in (1, 3, 1 << 10):
+        prm_b = pkg.Phase1Parameters.new_full(name, 0, power, bs)
+        key = pkg.PrivateKey(tau, alpha, beta, pk)
+        assert pkg.phase1_cli.computation(ch0, prm_b, key)[64:-len(pk)] == resp[64:-len(pk)]
+    pkg.transform_pok_and_correctness(f("c0"), f("v.c.h"), pkg.CheckForCorrectness.Full, f("r0"), f("v.r.h"), pkg.CheckForCorrectness.Full,
+                                      f("c1"), f("c1.h"), pkg.SubgroupCheckMode.Direct, True, prm)
+    nc = open(f("c1"), "rb").read()
+    assert nc == P.new_challenge_from_response(p, resp)
+    assert open(f("c1.h"), "rb").read() == P.calculate_hash(nc)
+    # Full mode runs the before/after checks: a response whose beta_g2 was moved by another factor is refused
+    G2 = Group(c, 2)
+    end = p.contribution_size - p.public_key_size
+    bad_b = serde.write_point(G2, G2.mul(G2.gen, (beta + 1) % c.r), True)
+    bad = resp[:end - G2.comp_size] + bad_b + resp[end:]
+    open(f("bad"), "wb").write(bad)
+    with pytest.raises(pkg.PtauError) as e:
+        pkg.transform_pok_and_correctness(f("c0"), f("b.c.h"), pkg.CheckForCorrectness.No, f("bad"), f("b.r.h"), pkg.CheckForCorrectness.OnlyNonZero,
+                                          f("bad.nc"), f("bad.nc.h"), pkg.SubgroupCheckMode.Auto, False, prm)
+    assert e.value.code == -6
+    # the accumulator a Full-mode contribution leaves passes the aggregate ratio check
+    pkg.transform_ratios(nc, pkg.CheckForCorrectness.Full, prm)
+
+
+def test_full_size_verify_chunk_config5(pkg, cref, tmp_path):
+    """BASELINE configs[4] shape, one chunk: verification_and_decompress of chunk 0 of the 2^20 BLS12-377 ceremony (3 * 2^20 G1
+    + 2^20 + 1 G2 elements, ratio check on, proofs of knowledge on).  The new challenge is checked against the C oracle's
+    decompress on sampled ranges of ALL FIVE vectors, the hash chain against BLAKE2b of the files, and a single swapped pair
+    deep inside a vector is caught by the ratio check."""
+    name, lg = "bls12_377", 20
+    n = 1 << lg
+    c = CURVES[name]
+    prm = pkg.Phase1Parameters.new_chunk(name, 0, 0, n, 0, lg, n)
+    f = lambda s: str(tmp_path / s)
+    pkg.new_challenge(f("c0"), f("c0.h"), prm)
+    seed = bytes(range(7, 71))
+    pkg.phase1_cli.contribute_seeded(f("c0"), f("c0.h2"), f("r0"), f("r0.h"), pkg.CheckForCorrectness.No, pkg.BatchExpMode.Auto, prm, seed)
+    pkg.transform_pok_and_correctness(f("c0"), f("v.c.h"), pkg.CheckForCorrectness.No, f("r0"), f("v.r.h"), pkg.CheckForCorrectness.OnlyNonZero,
+                                      f("c1"), f("c1.h"), pkg.SubgroupCheckMode.Auto, True, prm)
+    resp, nc = open(f("r0"), "rb").read(), open(f("c1"), "rb").read()
+    assert nc[:64] == pkg.calculate_hash(resp) == open(f("v.r.h"), "rb").read()
+    assert open(f("c1.h"), "rb").read() == pkg.calculate_hash(nc)
+    g1c, g1u, g2c, g2u = 48, 96, 96, 192
+    vecs = [(1, n, g1c, g1u), (2, n, g2c, g2u), (1, n, g1c, g1u), (1, n, g1c, g1u), (2, 1, g2c, g2u)]
+    oc, ou, k = 64, 64, 192
+    for grp, cnt, cs, us in vecs:
+        for lo in sorted({0, max(0, cnt // 2 - k // 2), max(0, cnt - k)}):
+            m = min(k, cnt - lo)
+            exp = cref.decompress(name, grp, resp[oc + lo * cs:oc + (lo + m) * cs], m)
+            assert nc[ou + lo * us:ou + (lo + m) * us] == exp, (grp, lo)
+        oc += cnt * cs
+        ou += cnt * us
+    assert oc == prm.contribution_size - prm.public_key_size and ou == prm.accumulator_size
+    # tamper deep inside alpha_g1: swap elements 600000 and 600001 (both still valid subgroup points)
+    off = 64 + n * g1c + n * g2c + 600000 * g1c
+    bad = bytearray(resp)
+    bad[off:off + g1c], bad[off + g1c:off + 2 * g1c] = bad[off + g1c:off + 2 * g1c], bad[off:off + g1c]
+    open(f("bad"), "wb").write(bytes(bad))
+    del bad, resp, nc
+    with pytest.raises(pkg.PtauError) as e:
+        pkg.transform_pok_and_correctness(f("c0"), f("b.c.h"), pkg.CheckForCorrectness.No, f("bad"), f("b.r.h"), pkg.CheckForCorrectness.OnlyNonZero,
+                                          f("bad.nc"), f("bad.nc.h"), pkg.SubgroupCheckMode.Auto, True, prm)
+    assert e.value.code == -6

@@ -244,3 +244,32 @@ def test_base_field_arithmetic_on_host(name):
         root = int.from_bytes(o[6 * B + 1:7 * B + 1], "little")
         assert (root * root % p == a) if is_res else root == 0
         assert o[7 * B + 1] == (1 if a == 0 else (2 if a > half else 0))
+
+
+def test_rust_shim_declarations_match_the_header():
+    """rust-shim/src/lib.rs cannot be compiled here (no Rust toolchain): at least every `fn ptau_*` it declares must be a
+    function of include/ptau.h with the same number of parameters, and the repr(C) structs must list the header's fields."""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "ptau.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    c_funcs = {}
+    for m in re.finditer(r"\b(?:int|void|const char \*)\s*(ptau_\w+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
+        args = m.group(2).strip()
+        c_funcs[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
+    rs = open(os.path.join(ROOT, "rust-shim", "src", "lib.rs")).read()
+    ext = rs[rs.index('extern "C" {'):]
+    ext = ext[:ext.index("\n}\n")]
+    rust_funcs = {}
+    for m in re.finditer(r"pub fn (ptau_\w+)\s*\((.*?)\)\s*(?:->\s*[^;]+)?;", ext, flags=re.S):
+        args = m.group(2).strip()
+        rust_funcs[m.group(1)] = 0 if not args else args.count(":")
+    assert len(rust_funcs) >= 19
+    for name, n in rust_funcs.items():
+        assert name in c_funcs, "%s is not declared in include/ptau.h" % name
+        assert c_funcs[name] == n, "%s: %d parameters in Rust, %d in C" % (name, n, c_funcs[name])
+    for field in ("curve", "proving_system", "contribution_mode", "power", "chunk_index", "chunk_size", "batch_size"):
+        assert re.search(r"pub %s: [iu](32|64)" % field, rs), field
+    # and every symbol the header declares is exported by the library and listed in the ctypes mirror
+    from conftest import load_package
+    pkg = load_package()
+    assert set(c_funcs) == set(pkg._lib.DECLARED_SYMBOLS)
