@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """bench.py — G1 point-updates/s of the chunk tau-update (BASELINE.json metric), one rank per GPU.
 
-Step = one pass of the hot path over one chunk vector: the tau-update of the 2^20-point tauG1
-vector of a BLS12-377 power-20 chunk (BASELINE configs[1]), device-resident in and out
-(uncompressed challenge points -> compressed response points).  N > 1: every rank updates its own
-chunk (independent chunks, no data-path collective) -> weak scaling.
+Step = one pass of the hot path over one chunk vector: by default (--config 2 = BASELINE configs[1], the configuration the
+metric is quoted on) the tau-update of the 2^20-point tauG1 vector of a BLS12-377 power-20 chunk, device-resident in and out
+(uncompressed challenge points -> compressed response points).  --config 3 / 4 run the tauG1 vector of one BW6-761 (2^18) /
+MNT4-753 (2^16) chunk and list the other groups of that config; --config 5 times the verification of a 2^20 BLS12-377 chunk.
+N > 1: every rank updates its own chunk (independent chunks, no data-path collective) -> weak scaling.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -21,7 +22,6 @@ sys.path.insert(0, ROOT)
 BLS_R = 0x12ab655e9a2ca55660b44d1e5c37b00159aa76fed00000010a11800000000001
 G1_GEN_X = 0x008848defe740a67c8fc6225bf87ff5485951e2caa9d41bb188282c8bd37cb5cd5481512ffcd394eeab9b16eb21be9ef
 G1_GEN_Y = 0x01914a69c5102eff1f674f5d30afeec4bd7fb348ca3e52d96d182ad44fb82305c2fe3d3634a9591afd82de55559c8ea6
-ALGO_BYTES_PER_UPDATE = 96 + 48      # uncompressed read + compressed write per BLS12-377 G1 update
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
@@ -51,44 +51,66 @@ def usable_cores():
     return min(n, int(os.environ.get("PTAU_BENCH_CPU_THREADS", "64")))
 
 
-def pmc_traffic():
-    """HBM bytes per scalar_mul_kernel launch from the committed rocprofv3 PMC summary (profiles/)."""
+def cpu_model():
     try:
-        import glob
-        f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))[-1]
-        d = json.load(open(f))
-        k = d["kernels"]
-        for name in ("window_scalar_mul_kernel<BlsG1>", "window_scalar_mul_kernel", "scalar_mul_kernel"):
-            if name in k and "hbm_bytes_per_launch" in k[name]:
-                return k[name]["hbm_bytes_per_launch"], os.path.basename(f)
-        return None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
     except Exception:
-        return None, None
+        pass
+    return "unknown CPU"
 
 
-def cpu_baseline(sample_points, chal_bytes, start, tau):
-    """The C oracle ("port") timed on this host's cores over a bounded sample of the same workload."""
+def cpu_baseline(curve, group, sample_points, chal_bytes, start, tau, single_core=True):
+    """The C oracle ("port": ark-ec's MSB-first double-and-add with mixed additions + batch normalisation, the algorithm the
+    reference's batch_exp runs; 64-bit CIOS Montgomery, no assembly) timed on this host over a bounded sample of the same
+    vector: all usable cores, and one core on a smaller slice."""
     from oracle import cref
     cores = usable_cores()
     cref.lib()
     t0 = time.time()
-    out = cref.apply_powers("bls12_377", 1, chal_bytes, sample_points, start, tau, None, False, True, nthreads=cores)
+    out = cref.apply_powers(curve, group, chal_bytes, sample_points, start, tau, None, False, True, nthreads=cores)
     dt = time.time() - t0
-    return out, {"value": sample_points / dt, "unit": "G1 point-updates/s", "cores": cores, "kind": "port",
-                 "sample": "%d of the 2^20 tauG1 points of the same chunk, C oracle (oracle/c), %d threads, %.1f s wall"
-                           % (sample_points, cores, dt)}
+    res = {"value": sample_points / dt, "unit": "G1 point-updates/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+           "sample": "%d points of the same vector, C oracle (oracle/c), %d threads, %.1f s wall" % (sample_points, cores, dt)}
+    if single_core:
+        usz = len(chal_bytes) // sample_points
+        m = max(1, min(sample_points, sample_points // max(1, cores) // 2))
+        t0 = time.time()
+        one = cref.apply_powers(curve, group, chal_bytes[:m * usz], m, start, tau, None, False, True, nthreads=1)
+        d1 = time.time() - t0
+        if one != out[:len(one)]:
+            raise SystemExit("CPU oracle disagrees with itself across thread counts")
+        res["single_core"] = {"value": m / d1, "sample": "%d points, 1 thread, %.1f s wall" % (m, d1)}
+    return out, res
 
 
-def whole_chunk_extras(pkg, log2n, dev):
+def initial_challenge_file(pkg, curve, prm, path, hash_path):
+    """phase1_cli::new_challenge; on MNT4-753 / MNT6-753 through the caller-supplied-generators form (the product holds no
+    G2 generator for them: the golden fixture's synthetic order-r point is read as data)."""
+    if not curve.startswith("mnt"):
+        pkg.new_challenge(path, hash_path, prm)
+        return
+    L = pkg.load_library()
+    cid = pkg.phase1_cli.curve_from_str(curve)
+    chal, n1 = golden_generator(curve, 2)
+    u1, u2 = L.ptau_point_size(cid, 1, 0), L.ptau_point_size(cid, 2, 0)
+    buf = pkg.phase1_cli.initialization_with_generators(prm, pkg.phase1_cli.generator(curve, 1), chal[64 + n1 * u1:64 + n1 * u1 + u2])
+    open(path, "wb").write(buf)
+    open(hash_path, "wb").write(pkg.calculate_hash(buf))
+
+
+def whole_chunk_extras(pkg, curve, power, log2n, dev):
     """Second half of the BASELINE metric ("chunks verified/sec") and the whole-chunk contribution, on chunk 0 of a
-    BLS12-377 power-`log2n` ceremony with chunk_size 2^log2n (3*2^n G1 + 2^n+1 G2 elements), through the FILE-level
+    power-`power` ceremony of `curve` with chunk_size 2^log2n (all five vectors), through the FILE-level
     entry points the operator calls (phase1_cli::contribute / transform_pok_and_correctness: mmap'd files on tmpfs,
     BLAKE2b of every file, `.hash` side files, PCIe both ways, pairing tail).  Untimed set-up: new_challenge -> one
     contribution; timed: verify (ratio_check on / off) and a second contribution of the verified new challenge."""
     import shutil
     import tempfile
     n = 1 << log2n
-    prm = pkg.Phase1Parameters.new_chunk("bls12_377", 0, 0, n, 0, log2n, n)
+    prm = pkg.Phase1Parameters.new_chunk(curve, 0, 0, n, 0, power, n)
+    n1, n2 = prm.g1_chunk_size, prm.other_chunk_size
     seed0, seed1 = b"bench seed 0".ljust(64, b"."), b"bench seed 1".ljust(64, b".")
     # the coordinator hands a contributor a challenge that came out of a verifier's subgroup checks: the operator-side
     # integration asserts that (INTEGRATION.md) and gets the endomorphism path; plain Auto is exact on any curve point
@@ -96,11 +118,12 @@ def whole_chunk_extras(pkg, log2n, dev):
     base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
     d = tempfile.mkdtemp(prefix="ptau_bench_", dir=base)
     f = lambda name: os.path.join(d, name)
-    out = {"workload": "BLS12-377 power %d chunk 0, chunk_size 2^%d: %d G1 + %d G2 elements; challenge %d B, response %d B; "
-                       "file-level entry points, files on %s" % (log2n, log2n, 3 * n, n + 1, prm.accumulator_size,
+    elems = n1 + 3 * n2 + 1
+    out = {"workload": "%s power %d chunk 0, chunk_size 2^%d: %d G1 + %d G2 elements; challenge %d B, response %d B; "
+                       "file-level entry points, files on %s" % (curve, power, log2n, n1 + 2 * n2, n2 + 1, prm.accumulator_size,
                                                                   prm.contribution_size, base or "the default tmp dir")}
     try:
-        pkg.new_challenge(f("c0"), f("c0.hash"), prm)
+        initial_challenge_file(pkg, curve, prm, f("c0"), f("c0.hash"))
         pkg.phase1_cli.contribute_seeded(f("c0"), f("c0.hash2"), f("r0"), f("r0.hash"), pkg.CheckForCorrectness.No, pkg.BatchExpMode.Auto,
                                          prm, seed0, device=dev)
         t0 = time.perf_counter()
@@ -109,7 +132,7 @@ def whole_chunk_extras(pkg, log2n, dev):
                                           True, prm, device=dev)
         dt = time.perf_counter() - t0
         tm = pkg.phase1_cli.last_timing(dev)
-        out["verify_chunk"] = {"seconds": dt, "chunks_verified_per_s": 1.0 / dt, "elements_per_s": (4 * n + 1) / dt,
+        out["verify_chunk"] = {"seconds": dt, "chunks_verified_per_s": 1.0 / dt, "elements_per_s": elems / dt,
                                "includes": "3 BLAKE2b digests (one host thread per file, overlapped with the device), compute_g2_s + 3 proofs "
                                            "of knowledge + 5 chunk-0 before/after checks, sqrt decompression, non-zero + subgroup check of "
                                            "every element, power_pairs of 4 vectors, 4 power-ratio pairing checks, new challenge written, "
@@ -123,19 +146,23 @@ def whole_chunk_extras(pkg, log2n, dev):
                                           False, prm, device=dev)
         dt2 = time.perf_counter() - t0
         out["verify_chunk_skip_ratio_check"] = {"seconds": dt2, "chunks_verified_per_s": 1.0 / dt2}
-        for tag, mode, what in (("contribute_chunk", verified, "Auto | INPUT_IN_SUBGROUP (challenge produced by the verification above: endomorphism path)"),
-                                ("contribute_chunk_exact", pkg.BatchExpMode.Auto, "Auto, CheckForCorrectness::No (exact on any curve point: plain windows)")):
+        modes = [("contribute_chunk_exact", pkg.BatchExpMode.Auto, "Auto, CheckForCorrectness::No (exact on any curve point: plain windows)")]
+        if not curve.startswith("mnt"):
+            modes.insert(0, ("contribute_chunk", verified, "Auto | INPUT_IN_SUBGROUP (challenge produced by the verification above: endomorphism path)"))
+        for tag, mode, what in modes:
             if os.path.exists(f("r1")):
                 os.remove(f("r1"))
             t0 = time.perf_counter()
             pkg.phase1_cli.contribute_seeded(f("c1"), f("c1.hash2"), f("r1"), f("r1.hash"), pkg.CheckForCorrectness.No, mode, prm, seed1, device=dev)
             dt3 = time.perf_counter() - t0
             tm = pkg.phase1_cli.last_timing(dev)
-            out[tag] = {"seconds": dt3, "chunks_per_s": 1.0 / dt3, "g1_equiv_updates_per_s": (4 * n + 1) / dt3, "batch_exp_mode": what,
+            out[tag] = {"seconds": dt3, "chunks_per_s": 1.0 / dt3, "g1_equiv_updates_per_s": elems / dt3, "batch_exp_mode": what,
                         "includes": "phase1_cli::contribute on files from a seed: key generation, BLAKE2b(challenge) overlapped, 5 vectors "
                                     "updated (PCIe both ways), public key + BLAKE2b(response) + msync",
                         "device_ms": tm["kernel_ms"], "h2d_ms": tm["h2d_ms"], "d2h_ms": tm["d2h_ms"]}
         assert open(f("c1"), "rb").read(64) == open(f("v.r.hash"), "rb").read()   # new challenge extends the response it verified
+        if curve != "bls12_377":
+            return out
         # several in-process lanes on ONE GPU (the operator's --max-in-process-lane, contribute.rs:120-121,467-492): the
         # library serialises only the device section of a call, so one lane's BLAKE2b overlaps another lane's kernels
         import threading
@@ -162,8 +189,8 @@ def whole_chunk_extras(pkg, log2n, dev):
                 out.setdefault("lanes", {})["%s_%d_lanes" % (name, lanes)] = {"seconds": dtl, "chunks_per_s": lanes / dtl}
         # whole-transcript tail (BASELINE configs[4]: verify_transcript's combine + transform_ratios): the round's second
         # chunk (tauG1 only, 2^n - 1 elements) contributed with the same key, both responses combined, ratio checks run
-        prm1 = pkg.Phase1Parameters.new_chunk("bls12_377", 0, 1, n, 0, log2n, n)
-        full = pkg.Phase1Parameters.new_full("bls12_377", 0, log2n, n)
+        prm1 = pkg.Phase1Parameters.new_chunk(curve, 0, 1, n, 0, log2n, n)
+        full = pkg.Phase1Parameters.new_full(curve, 0, log2n, n)
         pkg.new_challenge(f("d0"), f("d0.hash"), prm1)
         pkg.phase1_cli.contribute_seeded(f("d0"), f("d0.hash2"), f("s0"), f("s0.hash"), pkg.CheckForCorrectness.No, pkg.BatchExpMode.Auto, prm1,
                                          seed0, device=dev)
@@ -183,13 +210,81 @@ def whole_chunk_extras(pkg, log2n, dev):
     return out
 
 
+# ---- per-config workloads (BASELINE.json configs[1..4]) -----------------------------------------------------------------
+# (curve, group, log2 points of the vector one step updates, ceremony power, log2 chunk_size, limbs of the base field as the
+#  kernels hold it, extension degree, GLV/GLS available).  Algorithmic bytes per update = uncompressed read + compressed
+# write = 3 x the compressed size: 144 / 288 / 285 / 570 / 855 B.
+CONFIGS = {
+    2: {"groups": [("bls12_377", 1, 20)], "power": 20, "log2_chunk": 20,
+        "workload": "BLS12-377 phase-1 power 20, chunk_size 2^20: tauG1 vector of one chunk per GPU"},
+    3: {"groups": [("bw6", 1, 18), ("bw6", 2, 18)], "power": 20, "log2_chunk": 18,
+        "workload": "BW6-761 phase-1 power 20, chunk_size 2^18 (8 chunks, one per GPU): tauG1 vector of one chunk per GPU"},
+    4: {"groups": [("mnt4_753", 1, 16), ("mnt4_753", 2, 16), ("mnt6_753", 1, 16), ("mnt6_753", 2, 16)], "power": 18, "log2_chunk": 16,
+        "workload": "MNT4-753 + MNT6-753 phase-1 power 18, chunk_size 2^16: tauG1 vector of one MNT4-753 chunk per GPU"},
+}
+KERNEL_TAG = {("bls12_377", 1): "BlsG1", ("bls12_377", 2): "BlsG2", ("bw6", 1): "Bw6G1", ("bw6", 2): "Bw6G2",
+              ("mnt4_753", 1): "Mnt4G1", ("mnt4_753", 2): "Mnt4G2", ("mnt6_753", 1): "Mnt6G1", ("mnt6_753", 2): "Mnt6G2"}
+FIELD_LIMBS = {"bls12_377": 13, "bw6": 24, "mnt4_753": 26, "mnt6_753": 26}     # 29-bit limbs except BW6-761 (32-bit)
+SCALAR_BITS = {"bls12_377": 253, "bw6": 377, "mnt4_753": 753, "mnt6_753": 753}
+MAC_PEAK = 32.7e12        # measured v_mad_u64_u32 issue peak, lane-MACs/s chip-wide (profiles/r01_ubench_issue.txt)
+
+
+def macs_per_update(curve, group, endo):
+    """32x32->64 multiply-accumulates of one prime-field G1-type update, from the formulas the kernel runs:
+    product 2 N^2, square N^2 + N (N + 1) / 2; doubling 2M + 5S (a = 0) or 3M + 6S (+ a small a * Z^4 chain); full addition
+    11M + 5S; table of 8 multiples by 7 mixed additions (7M + 4S); signed 4-bit windows (15/16 of the digits are non-zero).
+    None for the extension-field groups (their base-product count depends on the lane mapping; not modelled)."""
+    if group != 1 and curve != "bw6":
+        return None
+    n = FIELD_LIMBS[curve]
+    m, sq = 2 * n * n, n * n + n * (n + 1) // 2
+    a_zero = curve in ("bls12_377", "bw6")
+    dbl = 2 * m + 5 * sq if a_zero else 3 * m + 6 * sq
+    add, madd = 11 * m + 5 * sq, 7 * m + 4 * sq
+    bits = SCALAR_BITS[curve]
+    if endo and a_zero:
+        half = 128 if curve == "bls12_377" else 192
+        windows = half // 4
+        return (4 * windows - 4) * dbl + 2 * windows * 15 // 16 * add + windows * 15 // 16 * m + 7 * madd
+    windows = (bits + 3 + 3) // 4
+    return (4 * windows - 4) * dbl + windows * 15 // 16 * add + 7 * madd
+
+
+def pmc_for(tag):
+    """Counters of window_scalar_mul_kernel<tag> from the newest committed rocprofv3 PMC summary (profiles/)."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc*.json"))):
+        try:
+            k = json.load(open(f)).get("kernels", {})
+        except Exception:
+            continue
+        for name, d in k.items():
+            if name.startswith("window_scalar_mul_kernel") and ("<%s>" % tag) in name and "hbm_bytes_per_launch" in d:
+                best = (d, os.path.basename(f))
+    return best if best else (None, None)
+
+
+def golden_generator(curve, group):
+    """Uncompressed generator bytes.  MNT G2: the product holds none — element 0 of tauG2 of the committed
+    golden challenge (a synthetic order-r point; any order-r base serves a throughput measurement) is read as data."""
+    doc = json.load(open(os.path.join(ROOT, "tests", "golden", "phase1_%s.json" % curve)))
+    ch = doc["chunks"][0]
+    chal = bytes.fromhex(ch["challenge"])
+    n1 = min(doc["chunk_size"], (2 << doc["power"]) - 1)
+    return chal, n1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--log2-points", type=int, default=20)
-    ap.add_argument("--cpu-sample", type=int, default=1 << 20, help="points the CPU oracle updates (parity check + cpu_baseline; ~13 s at 16 threads)")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5),
+                    help="BASELINE.json configs[] index: 2 = BLS12-377 2^20 G1 tau-update (the metric's config, default), 3 = BW6-761 chunk, "
+                         "4 = MNT4/MNT6 chunks, 5 = verification of a 2^20 BLS12-377 chunk")
+    ap.add_argument("--log2-points", type=int, default=None, help="override the vector length of the config")
+    ap.add_argument("--cpu-sample", type=int, default=None, help="points the CPU oracle updates (parity check + cpu_baseline)")
     ap.add_argument("--no-extras", action="store_true", help="skip the whole-chunk contribute / verify measurements")
     args = ap.parse_args()
 
@@ -217,28 +312,8 @@ def main():
     pkg = load_pkg()
     L = pkg.load_library()
     dev = local_rank
-    n = 1 << args.log2_points
-    nl = L.ptau_fr_limbs(0)
     eb = ctypes.create_string_buffer(256)
-
     ENDO = int(pkg.BatchExpMode.Auto) | pkg.phase1_cli.INPUT_IN_SUBGROUP
-
-    def run(d_in, cin, d_out, cout, count, start, tau, mode=0):
-        rc = L.ptau_apply_powers_dev(0, 1, ctypes.c_void_p(d_in.data_ptr()), cin, ctypes.c_void_p(d_out.data_ptr()), cout,
-                                     count, start, pkg._lib.limbs(tau, nl), None, 0, mode, dev, eb, len(eb))
-        if rc:
-            raise RuntimeError("ptau_apply_powers_dev rc=%d: %s" % (rc, eb.value.decode()))
-
-    # synthetic chunk (rank r owns chunk index r of a power-20 ceremony, chunk_size 2^20):
-    # a genuine accumulator vector [s^(start+i) G1] made on the device from the generator (untimed).
-    start = rank * n
-    s, tau = det_scalar("bench/s"), det_scalar("bench/tau")
-    gen = G1_GEN_X.to_bytes(48, "little") + G1_GEN_Y.to_bytes(48, "little")
-    d_gen = torch.frombuffer(bytearray(gen * n), dtype=torch.uint8).cuda()
-    d_chal = torch.empty(n * 96, dtype=torch.uint8, device="cuda")
-    d_resp = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
-    run(d_gen, 0, d_chal, 0, n, start, s, ENDO)
-    del d_gen
 
     def barrier():
         torch.cuda.synchronize()
@@ -246,29 +321,70 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.config == 5:
+        return bench_verify(args, pkg, dev, rank, world, dist, backend, barrier)
+
+    cfg = CONFIGS[args.config]
+
+    def make_vector(curve, group, n, start):
+        """A genuine accumulator vector [s^(start+i) G] of n uncompressed points, made on the device (untimed)."""
+        cid = pkg.phase1_cli.curve_from_str(curve)
+        usz, csz = L.ptau_point_size(cid, group, 0), L.ptau_point_size(cid, group, 1)
+        if curve.startswith("mnt") and group == 2:
+            chal, n1 = golden_generator(curve, group)
+            u1 = L.ptau_point_size(cid, 1, 0)
+            gen = chal[64 + n1 * u1:64 + n1 * u1 + usz]
+        else:
+            gen = pkg.phase1_cli.generator(curve, group)
+        nl = L.ptau_fr_limbs(cid)
+        d_gen = torch.frombuffer(bytearray(gen * n), dtype=torch.uint8).cuda()
+        d_chal = torch.empty(n * usz, dtype=torch.uint8, device="cuda")
+        d_resp = torch.empty(n * csz, dtype=torch.uint8, device="cuda")
+        s = det_scalar("bench/s") % (1 << 250)
+
+        def run(d_in, cin, d_out, cout, tau, mode=0):
+            rc = L.ptau_apply_powers_dev(cid, group, ctypes.c_void_p(d_in.data_ptr()), cin, ctypes.c_void_p(d_out.data_ptr()), cout,
+                                         n, start, pkg._lib.limbs(tau, nl), None, 0, mode, dev, eb, len(eb))
+            if rc:
+                raise RuntimeError("ptau_apply_powers_dev rc=%d: %s" % (rc, eb.value.decode()))
+        run(d_gen, 0, d_chal, 0, s, ENDO)
+        del d_gen
+        return d_chal, d_resp, run, usz, csz
+
+    # ---- the timed workload: first group of the config -----------------------------------------------------------------
+    curve, group, lg = cfg["groups"][0]
+    if args.log2_points is not None:
+        lg = args.log2_points
+    n = 1 << lg
+    start = rank * n      # rank r owns chunk index r (chunk_size = n): independent chunks, no data-path collective
+    tau = det_scalar("bench/tau") % (1 << 250)      # below every curve's group order
+    d_chal, d_resp, run, usz, csz = make_vector(curve, group, n, start)
     for _ in range(args.warmup):
-        run(d_chal, 0, d_resp, 1, n, start, tau)
+        run(d_chal, 0, d_resp, 1, tau)
     barrier()
     t0 = time.perf_counter()
     smul_ms = norm_ms = 0.0
     for _ in range(args.steps):
-        run(d_chal, 0, d_resp, 1, n, start, tau)
+        run(d_chal, 0, d_resp, 1, tau)
         tm = pkg.phase1_cli.last_timing(dev)      # HIP events on the library's own stream
         smul_ms += tm["scalar_mul_ms"]
         norm_ms += tm["normalize_ms"]
     barrier()
     dt = time.perf_counter() - t0
-    # the same step on the endomorphism path (GLV; membership asserted by the caller — what an operator that trusts its
+    # the same step on the endomorphism path (membership asserted by the caller — what an operator that trusts its
     # coordinator's verifier runs): reported next to `value`, never as `value`
-    run(d_chal, 0, d_resp, 1, n, start, tau, ENDO)
-    endo_ms = 0.0
-    te = time.perf_counter()
-    for _ in range(args.steps):
-        run(d_chal, 0, d_resp, 1, n, start, tau, ENDO)
-        endo_ms += pkg.phase1_cli.last_timing(dev)["scalar_mul_ms"]
-    torch.cuda.synchronize()
-    dte = time.perf_counter() - te
-    run(d_chal, 0, d_resp, 1, n, start, tau)      # d_resp again holds the exact path's output (parity sample below)
+    endo = None
+    if not curve.startswith("mnt"):
+        run(d_chal, 0, d_resp, 1, tau, ENDO)
+        endo_ms = 0.0
+        te = time.perf_counter()
+        for _ in range(args.steps):
+            run(d_chal, 0, d_resp, 1, tau, ENDO)
+            endo_ms += pkg.phase1_cli.last_timing(dev)["scalar_mul_ms"]
+        torch.cuda.synchronize()
+        dte = time.perf_counter() - te
+        endo = (n * args.steps / dte, endo_ms / args.steps)
+        run(d_chal, 0, d_resp, 1, tau)      # d_resp again holds the exact path's output (parity sample below)
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -277,42 +393,145 @@ def main():
     if rank == 0:
         value = world * n * args.steps / dt
         kernel_s = (smul_ms / args.steps) / 1e3
-        achieved = ALGO_BYTES_PER_UPDATE * n / kernel_s / 1e9
-        # parity check + CPU baseline on a bounded sample of the same chunk (the timed baseline only at N = 1: at
+        algo = 3 * csz
+        achieved = algo * n / kernel_s / 1e9
+        # parity check + CPU baseline on a bounded sample of the same vector (the timed baseline only at N = 1: at
         # N > 1 the other ranks would idle behind rank 0's host cores, so only a small parity sample is checked)
-        sample = min(args.cpu_sample if world == 1 else 4096, n)
-        chal_host = d_chal[:sample * 96].cpu().numpy().tobytes()
-        ref, base = cpu_baseline(sample, chal_host, start, tau)
+        default_sample = {"bls12_377": 1 << 20, "bw6": 1 << 16, "mnt4_753": 1 << 15, "mnt6_753": 1 << 15}[curve]
+        sample = min((args.cpu_sample if args.cpu_sample is not None else default_sample) if world == 1 else 2048, n)
+        chal_host = d_chal[:sample * usz].cpu().numpy().tobytes()
+        ref, base = cpu_baseline(curve, group, sample, chal_host, start, tau, single_core=(world == 1))
         if world > 1:
             base = None
-        got = d_resp[:sample * 48].cpu().numpy().tobytes()
+        got = d_resp[:sample * csz].cpu().numpy().tobytes()
         if got != ref:
             raise SystemExit("PARITY FAILURE: GPU response differs from the CPU oracle on the sampled points")
-        traffic, traffic_src = pmc_traffic()
+        tag = KERNEL_TAG[(curve, group)]
+        pmc, pmc_src = pmc_for(tag)
+        traffic = pmc["hbm_bytes_per_launch"] if pmc else None
+        macs = macs_per_update(curve, group, endo=False)
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic, "traffic_source": pmc_src,
+                "traffic_ratio": (traffic / (algo * n)) if traffic else None,
+                "algorithmic_bytes_per_update": algo, "updates_per_launch": n,
+                "kernel": "window_scalar_mul_kernel<%s>" % tag, "kernel_ms": smul_ms / args.steps,
+                "normalize_kernel_ms": norm_ms / args.steps,
+                "macs_per_update": macs, "alu_peak_mac_per_s": MAC_PEAK,
+                "alu_frac": (macs * n / kernel_s / MAC_PEAK) if macs else None,
+                "note": "big-integer arithmetic: the kernel is bound by integer-multiplier issue, not by HBM — alu_frac (32x32->64 "
+                        "MACs/s over the measured v_mad_u64_u32 issue peak, profiles/r01_ubench_issue.txt) is the figure that "
+                        "measures kernel quality; frac is the contract's HBM fraction (DESIGN.md §4)"}
         name = ctypes.create_string_buffer(128)
         L.ptau_device_info(dev, name, 128, None, None)
-        extras = None
-        if world == 1 and not args.no_extras:
-            extras = whole_chunk_extras(pkg, args.log2_points, dev)
-        print(json.dumps({
+        out = {
             "metric": "G1 point-updates/sec per chunk (contribute)", "value": value, "unit": "G1 point-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": "BLS12-377 phase-1 power 20, chunk_size 2^20: tauG1 vector of one chunk per GPU "
-                                   "(2^%d points, uncompressed in -> compressed out, HBM-resident)" % args.log2_points,
-                       "points_per_step_per_gpu": n, "device": name.value.decode(), "parity": "bit-exact vs CPU oracle on %d sampled points" % sample},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "window_scalar_mul_kernel<BLS12-377 G1>", "kernel_ms": smul_ms / args.steps,
-                         "normalize_kernel_ms": norm_ms / args.steps,
-                         "note": "integer-ALU-bound by construction (~0.6 M 32x32->64 MACs per update vs 144 B; 58 % of the measured v_mad_u64_u32 issue peak): see DESIGN.md"},
+            "config": {"workload": cfg["workload"] + " (2^%d %s G%d points, uncompressed in -> compressed out, HBM-resident)" % (lg, curve, group),
+                       "baseline_config": args.config, "points_per_step_per_gpu": n, "device": name.value.decode(),
+                       "parity": "bit-exact vs CPU oracle on %d sampled points" % sample},
+            "roofline": roof,
             "cpu_baseline": base,
             "value_path": "BatchExpMode::Auto with CheckForCorrectness::No (the operator's contribute default): plain signed-window "
                           "multiplication, exact for ANY curve point",
-            "endomorphism_path": {"value": n * args.steps / dte, "unit": "G1 point-updates/s (this rank)", "kernel_ms": endo_ms / args.steps,
-                                  "batch_exp_mode": "Auto | PTAU_BATCH_EXP_INPUT_IN_SUBGROUP (GLV; same bytes on subgroup points)"},
-            "extras": extras,
-        }))
+        }
+        if endo:
+            em = macs_per_update(curve, group, endo=True)
+            out["endomorphism_path"] = {"value": endo[0], "unit": "G1 point-updates/s (this rank)", "kernel_ms": endo[1],
+                                        "alu_frac": (em * n / (endo[1] / 1e3) / MAC_PEAK) if em else None, "macs_per_update": em,
+                                        "batch_exp_mode": "Auto | PTAU_BATCH_EXP_INPUT_IN_SUBGROUP (GLV; same bytes on subgroup points)"}
+        # the other groups of the config, one launch size each (kernel-only, same entry point)
+        others = {}
+        for (c2, g2, lg2) in cfg["groups"][1:] if world == 1 else []:
+            n2 = 1 << lg2
+            dc, dr, run2, u2, cs2 = make_vector(c2, g2, n2, 0)
+            run2(dc, 0, dr, 1, tau)
+            run2(dc, 0, dr, 1, tau)
+            t2 = pkg.phase1_cli.last_timing(dev)
+            p2, _ = pmc_for(KERNEL_TAG[(c2, g2)])
+            m2 = macs_per_update(c2, g2, endo=False)
+            entry = {"updates_per_s": n2 / ((t2["scalar_mul_ms"] + t2["normalize_ms"]) / 1e3), "kernel_ms": t2["scalar_mul_ms"],
+                     "normalize_kernel_ms": t2["normalize_ms"], "points": n2, "algorithmic_bytes_per_update": 3 * cs2,
+                     "hbm_frac": 3 * cs2 * n2 / (t2["scalar_mul_ms"] / 1e3) / 1e9 / HBM_PEAK_GBS,
+                     "alu_frac": (m2 * n2 / (t2["scalar_mul_ms"] / 1e3) / MAC_PEAK) if m2 else None,
+                     "traffic_ratio": (p2["hbm_bytes_per_launch"] / (3 * cs2 * n2)) if p2 else None}
+            if not c2.startswith("mnt"):
+                run2(dc, 0, dr, 1, tau, ENDO)
+                entry["endomorphism_updates_per_s"] = n2 / (pkg.phase1_cli.last_timing(dev)["kernel_ms"] / 1e3)
+            others["%s_G%d" % (c2, g2)] = entry
+            del dc, dr
+        if others:
+            out["other_groups"] = others
+        if world == 1 and not args.no_extras:
+            out["extras"] = whole_chunk_extras(pkg, curve, cfg["power"] if args.log2_points is None else lg,
+                                               cfg["log2_chunk"] if args.log2_points is None else lg, dev)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def bench_verify(args, pkg, dev, rank, world, dist, backend, barrier):
+    """--config 5: verification of one 2^20 BLS12-377 chunk per GPU (BASELINE configs[4], second half of the metric).  A step =
+    phase1_cli::transform_pok_and_correctness on chunk 0 (files on tmpfs, ratio check on): the boundary of this path is the
+    file pair, so `value` includes PCIe and the BLAKE2b chain; the device-resident share is reported beside it."""
+    import shutil
+    import tempfile
+    import torch
+    lg = args.log2_points or 20
+    n = 1 << lg
+    prm = pkg.Phase1Parameters.new_chunk("bls12_377", 0, 0, n, 0, lg, n)
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    d = tempfile.mkdtemp(prefix="ptau_bench_v%d_" % rank, dir=base)
+    f = lambda s: os.path.join(d, s)
+    try:
+        pkg.new_challenge(f("c0"), f("c0.hash"), prm)
+        pkg.phase1_cli.contribute_seeded(f("c0"), f("c0.h2"), f("r0"), f("r0.hash"), pkg.CheckForCorrectness.No, pkg.BatchExpMode.Auto,
+                                         prm, b"bench verify seed".ljust(64, b"."), device=dev)
+
+        def step(k):
+            if os.path.exists(f("c1")):
+                os.remove(f("c1"))
+            pkg.transform_pok_and_correctness(f("c0"), f("v.c.hash"), pkg.CheckForCorrectness.No, f("r0"), f("v.r.hash"),
+                                              pkg.CheckForCorrectness.OnlyNonZero, f("c1"), f("c1.hash"), pkg.SubgroupCheckMode.Auto,
+                                              True, prm, device=dev)
+        for k in range(args.warmup):
+            step(k)
+        barrier()
+        t0 = time.perf_counter()
+        dev_ms = sub_ms = 0.0
+        for k in range(args.steps):
+            step(k)
+            tm = pkg.phase1_cli.last_timing(dev)
+            dev_ms += tm["kernel_ms"]
+            sub_ms += tm["subgroup_ms"]
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        if rank == 0:
+            assert open(f("c1"), "rb").read(64) == open(f("v.r.hash"), "rb").read()
+            elems = 4 * n + 1
+            sub_s = sub_ms / args.steps / 1e3
+            algo = 3 * n * 96 + (n + 1) * 192      # the membership kernels read every decompressed element once
+            print(json.dumps({
+                "metric": "chunks verified/sec", "value": world * args.steps / dt, "unit": "chunks verified/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+                "config": {"workload": "verify_transcript step on a 2^%d BLS12-377 ceremony: transform_pok_and_correctness of chunk 0 "
+                                       "(%d elements: challenge %d B, response %d B), ratio check + proofs of knowledge, files on %s; "
+                                       "PCIe and the BLAKE2b chain are inside the step (the path's boundary is the file pair)"
+                                       % (lg, elems, prm.accumulator_size, prm.contribution_size, base or "tmp"),
+                           "baseline_config": 5, "elements_per_step_per_gpu": elems},
+                "device_resident": {"kernel_ms_per_chunk": dev_ms / args.steps, "chunks_per_s": 1e3 / (dev_ms / args.steps)},
+                "roofline": {"bound": "hbm", "kernel": "endo_subgroup_kernel (G1 x3 vectors + G2)", "kernel_ms": sub_ms / args.steps,
+                             "achieved": algo / sub_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo / sub_s / 1e9 / HBM_PEAK_GBS,
+                             "traffic": None, "note": "membership tests are ~126 doublings per element: integer-ALU-bound, see DESIGN.md"},
+                "cpu_baseline": None}))
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -36,9 +36,11 @@ def main():
             c = row["Counter_Name"]
             acc[k][c] += float(row["Counter_Value"])
             launches[k][c].add((f, row.get("Dispatch_Id", row.get("Correlation_Id", ""))))
-            regs[k] = {"vgpr": int(row.get("VGPR_Count", 0) or 0), "accum_vgpr": int(row.get("Accum_VGPR_Count", 0) or 0),
-                       "sgpr": int(row.get("SGPR_Count", 0) or 0), "scratch": int(row.get("Scratch_Size", 0) or 0),
-                       "lds": int(row.get("LDS_Block_Size", 0) or 0)}
+            # NB rocprofv3's VGPR_Count column is NOT the allocation on gfx950's unified VGPR/AGPR file (it showed 128 for a
+            # kernel whose code object allocates 256): registers, spills and occupancy come from the code objects themselves —
+            # tools/kernel_resources.sh -> profiles/rNN_kernel_resources*.txt.  Scratch and LDS below are per-dispatch facts.
+            regs[k] = {"scratch_bytes_per_lane": int(row.get("Scratch_Size", 0) or 0), "lds_bytes_per_block": int(row.get("LDS_Block_Size", 0) or 0),
+                       "grid": int(row.get("Grid_Size", 0) or 0), "workgroup": int(row.get("Workgroup_Size", 0) or 0)}
     kernels = {}
     for k, cs in acc.items():
         d = dict(regs.get(k, {}))
@@ -48,6 +50,8 @@ def main():
             d[c + "_launches"] = n
         if "FETCH_SIZE_per_launch" in d and "WRITE_SIZE_per_launch" in d:
             d["hbm_bytes_per_launch"] = (2.0 * d["FETCH_SIZE_per_launch"] + d["WRITE_SIZE_per_launch"]) * 1024.0
+        if "SQ_WAIT_ANY_per_launch" in d and d.get("SQ_WAVE_CYCLES_per_launch"):
+            d["wait_any_frac_of_wave_cycles"] = d["SQ_WAIT_ANY_per_launch"] / d["SQ_WAVE_CYCLES_per_launch"]
         kernels[k] = d
     json.dump({"source": "rocprofv3 --pmc <counter> (separate passes) -- " + cmd,
                "unit_note": "FETCH_SIZE/WRITE_SIZE are KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half "
