@@ -224,7 +224,7 @@ CONFIGS = {
 }
 KERNEL_TAG = {("bls12_377", 1): "BlsG1", ("bls12_377", 2): "BlsG2", ("bw6", 1): "Bw6G1", ("bw6", 2): "Bw6G2",
               ("mnt4_753", 1): "Mnt4G1", ("mnt4_753", 2): "Mnt4G2", ("mnt6_753", 1): "Mnt6G1", ("mnt6_753", 2): "Mnt6G2"}
-FIELD_LIMBS = {"bls12_377": 13, "bw6": 24, "mnt4_753": 26, "mnt6_753": 26}     # 29-bit limbs except BW6-761 (32-bit)
+FIELD_LIMBS = {"bls12_377": 13, "bw6": 28, "mnt4_753": 26, "mnt6_753": 26}     # limbs of 29 bits (BW6-761: 28, one spare, so the element splits over a lane pair)
 SCALAR_BITS = {"bls12_377": 253, "bw6": 377, "mnt4_753": 753, "mnt6_753": 753}
 MAC_PEAK = 32.7e12        # measured v_mad_u64_u32 issue peak, lane-MACs/s chip-wide (profiles/r01_ubench_issue.txt)
 

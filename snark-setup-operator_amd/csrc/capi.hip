@@ -1511,7 +1511,7 @@ int ptau_check_same_ratio(int curve, const uint8_t *g1_a, const uint8_t *g1_b, c
     int r;
     switch (curve) {
     case PTAU_CURVE_BLS12_377: r = TatePairing<BlsFqR29, BlsFr, BlsG1Cfg, BlsG2Cfg, BlsPairingCfg>::check_same_ratio(g1_a, g1_b, g2_c, g2_d); break;
-    case PTAU_CURVE_BW6_761: r = TatePairing<Bw6Fq, Bw6Fr, Bw6G1Cfg, Bw6G2Cfg, Bw6PairingCfg>::check_same_ratio(g1_a, g1_b, g2_c, g2_d); break;
+    case PTAU_CURVE_BW6_761: r = TatePairing<Bw6FqR29, Bw6Fr, Bw6G1Cfg, Bw6G2Cfg, Bw6PairingCfg>::check_same_ratio(g1_a, g1_b, g2_c, g2_d); break;
     case PTAU_CURVE_MNT4_753: r = TatePairing<Mnt4FqR29, Mnt4Fr, Mnt4G1Cfg, Mnt4G2Cfg, Mnt4PairingCfg>::check_same_ratio(g1_a, g1_b, g2_c, g2_d); break;
     case PTAU_CURVE_MNT6_753: r = TatePairing<Mnt6FqR29, Mnt6Fr, Mnt6G1Cfg, Mnt6G2Cfg, Mnt6PairingCfg>::check_same_ratio(g1_a, g1_b, g2_c, g2_d); break;
     default: return err.fail(PTAU_E_ARG, "unknown curve id %d", curve);

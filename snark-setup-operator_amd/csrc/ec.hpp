@@ -13,12 +13,7 @@ namespace ptau {
 template <class F, class Cfg>
 struct CurveConsts {
     using B = typename F::Base;
-    PTAU_HD static B base_from(const uint32_t *p) {
-        B r;
-#pragma unroll
-        for (int i = 0; i < B::N; i++) r.l[i] = p[i];
-        return r;
-    }
+    PTAU_HD static B base_from(const uint32_t *p) { return B::load_const(p); }
     PTAU_HD static F coeff_a() {
         if constexpr (F::DEG == 1) return base_from(Cfg::A0);
         else if constexpr (F::DEG == 2) return F::make(base_from(Cfg::A0), base_from(Cfg::A1));

@@ -4,7 +4,7 @@
 // BLS12-377, MNT4-753 (D = 2) and MNT6-753 (D = 3)); NR is a small signed integer so the
 // non-residue product is a short addition chain instead of a field multiplication.
 #pragma once
-#include "fp29.hpp"
+#include "fpl.hpp"
 
 namespace ptau {
 
@@ -61,7 +61,7 @@ struct Fp2 {
     PTAU_HD static Fp2 make(const F &c0, const F &c1) { return {c0, c1}; }
     PTAU_HD static Fp2 make_pair_scaled(const Fp2 &a, int k) { return {F::mul_small(a.c0, k), F::mul_small(a.c1, k)}; }
     PTAU_HD static Fp2 conj(const Fp2 &a) { return {a.c0, F::neg(a.c1)}; }
-    static constexpr int LANES = 1;   // lanes of a wavefront that hold one element
+    static constexpr int LANES = F::LANES;   // lanes of a wavefront that hold one element (2 over a lane-split base field)
     __host__ __device__ __noinline__ static Fp2 inverse(const Fp2 &a) {
         F n = F::sub(F::sqr(a.c0), F::mul_small(F::sqr(a.c1), NR));
         F ni = F::inverse(n);
@@ -119,20 +119,7 @@ struct Fp2 {
 // Karatsuba (4 base products on 2 lanes = 2 per lane), complex squaring (1 per lane).  Every lane of a pair executes
 // the same instruction stream; all data-dependent branches in the callers are pair-uniform by construction
 // (is_zero / == combine both lanes).  Device only: the CPU emulation of the kernel bodies uses Fp2.
-PTAU_HD uint32_t lane_parity() {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return threadIdx.x & 1u;
-#else
-    return 0;
-#endif
-}
-PTAU_HD uint32_t lane_xchg(uint32_t v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
-#else
-    return v;
-#endif
-}
+// lane_parity() / lane_xchg(): fpl.hpp
 
 template <class F, int NR>
 struct Fp2L {
@@ -266,7 +253,7 @@ struct Fp3 {
     }
     PTAU_HD static Fp3 sqr(const Fp3 &a) { return mul(a, a); }
     PTAU_HD static Fp3 make(const F &c0, const F &c1, const F &c2) { return {c0, c1, c2}; }
-    static constexpr int LANES = 1;
+    static constexpr int LANES = F::LANES;
     __host__ __device__ __noinline__ static Fp3 inverse(const Fp3 &a) {
         F t0 = F::sub(F::sqr(a.c0), F::mul_small(F::mul(a.c1, a.c2), NR));
         F t1 = F::sub(F::mul_small(F::sqr(a.c2), NR), F::mul(a.c0, a.c1));
@@ -277,9 +264,7 @@ struct Fp3 {
     }
     // Frobenius a -> a^q
     PTAU_HD static Fp3 frobenius(const Fp3 &a) {
-        F c1, c2;
-#pragma unroll
-        for (int i = 0; i < F::N; i++) { c1.l[i] = F::Params::FROB3_C1[i]; c2.l[i] = F::Params::FROB3_C2[i]; }
+        const F c1 = F::load_const(F::Params::FROB3_C1), c2 = F::load_const(F::Params::FROB3_C2);
         return {a.c0, F::mul(a.c1, c1), F::mul(a.c2, c2)};
     }
     __host__ __device__ __noinline__ static Fp3 pow_limbs(const Fp3 &a, const uint32_t *e, int top_bit) {

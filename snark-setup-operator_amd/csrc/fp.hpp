@@ -81,6 +81,12 @@ struct Fp {
     using Params = P;
     uint32_t l[N];
 
+    PTAU_HD static Fp load_const(const uint32_t *c) {   // a constant given as N limbs
+        Fp r;
+#pragma unroll
+        for (int i = 0; i < N; i++) r.l[i] = c[i];
+        return r;
+    }
     PTAU_HD static Fp zero() {
         Fp r;
 #pragma unroll

@@ -36,6 +36,12 @@ struct Fp29 {
     static_assert(P::LB == 29, "parameter struct generated for another radix");
     uint32_t l[N];
 
+    PTAU_HD static Fp29 load_const(const uint32_t *c) {   // a constant given as N limbs
+        Fp29 r;
+#pragma unroll
+        for (int i = 0; i < N; i++) r.l[i] = c[i];
+        return r;
+    }
     PTAU_HD static Fp29 zero() {
         Fp29 r;
 #pragma unroll

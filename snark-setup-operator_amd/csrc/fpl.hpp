@@ -1,0 +1,382 @@
+// Prime-field element SPLIT OVER A LANE PAIR: the wide base fields (MNT4/MNT6-753: 26 limbs of 29 bits, BW6-761: 28) with
+// the low half of the limbs in the even lane and the high half in the odd lane.
+//
+// Why (profiles/r02_start/): with one 24-27-limb element per lane a Jacobian point is 72-80 VGPRs before any temporary, the
+// point operations live in private memory (3-10 KB of scratch per lane), the tau-update of a 2^18-point BW6-761 vector
+// moves 427 GB through the L2 for 75 MB of algorithmic traffic and runs at 30 % of the integer-multiplier peak; a
+// 2^16-point MNT chunk is 1024 waves, ONE per SIMD, with nothing to hide those loads behind.  Spread over two lanes an
+// element is 13-14 VGPRs per lane (a G1 point 39-42), the whole point arithmetic stays in registers with the product as a
+// register-ABI call, and the same chunk is twice as many waves.
+//
+// Same representation as Fp29<P> (fp29.hpp): Montgomery form with R = 2^(29 N), limbs of 29 bits, always fully reduced —
+// the even lane holds limbs [0, H), the odd lane limbs [H, N), H = N / 2 — so a lane-split kernel and a single-lane
+// kernel exchange values limb for limb (store_jac, kernels_impl.hpp).
+//
+// Product: operand scanning with the accumulator row distributed.  Iteration i adds a_i * b and m_i * p to N 64-bit
+// accumulators (H per lane: 2H bare v_mad_u64_u32 per lane, no carry instruction — 2N products below 2^58 fit 64 bits),
+// m_i comes from the even lane's position 0 and is broadcast by one DPP move, then the row shifts down one limb: the even
+// lane's position 0 leaves its carry to position 1, the odd lane's lowest accumulator crosses to the even lane's top.
+// MAC count per pair = 2 N^2, the same as the single-lane product scanning; the cross-lane price is ~12 plain
+// instructions per iteration.  Carry chains (add, sub, the final reduction) run in both lanes at once with a zero
+// carry-in; the even lane's carry-out is then folded into the odd lane's lowest limb(s) and only the (2^-29-rare) case
+// where that ripples further takes a lane-local slow path — no second pass.
+//
+// Device only (DPP quad_perm [1,0,3,2]); every cross-lane move is executed unconditionally by both lanes of a pair, and
+// every data-dependent branch in the callers is pair-uniform (is_zero / == combine both lanes).  Functions with no
+// bearing on throughput (inverse, square root, byte I/O) gather the element into each lane and run the Fp29 code
+// redundantly.
+#pragma once
+#include "fp29.hpp"
+
+namespace ptau {
+
+PTAU_HD uint32_t lane_parity() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return threadIdx.x & 1u;
+#else
+    return 0;
+#endif
+}
+PTAU_HD uint32_t lane_xchg(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+#else
+    return v;
+#endif
+}
+// the even (odd) lane's value in both lanes of every pair: one DPP move, no select
+PTAU_HD uint32_t lane_bcast_even(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xA0 /* quad_perm [0,0,2,2] */, 0xF, 0xF, true);
+#else
+    return v;
+#endif
+}
+PTAU_HD uint32_t lane_bcast_odd(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xF5 /* quad_perm [1,1,3,3] */, 0xF, 0xF, true);
+#else
+    return v;
+#endif
+}
+
+template <class P>
+struct FpL {
+    static constexpr int N = P::N;       // limbs of the whole element
+    static constexpr int H = N / 2;      // limbs per lane
+    static constexpr int N32 = P::N32;
+    static constexpr int LB = 29;
+    static constexpr uint32_t MASK = (1u << LB) - 1u;
+    static constexpr int DEG = 1;
+    static constexpr int LANES = 2;
+    static constexpr int BYTES = P::BYTES;
+    static constexpr bool MUL_OUT_OF_LINE = false;
+    static constexpr bool POINT_OPS_INLINE = true;   // point operations inline around register-ABI product calls
+    using Base = FpL<P>;
+    using Params = P;
+    using Full = Fp29<P>;                // the same element in one lane
+    static_assert(P::LB == 29 && N % 2 == 0, "lane-split fields need an even number of 29-bit limbs");
+    static_assert(2 * N <= 60, "accumulator row would overflow 64 bits");
+    uint32_t l[H];
+
+    PTAU_HD static bool hi_lane() { return lane_parity() != 0; }
+    // this lane's half of a compile-time constant given as N limbs
+    PTAU_HD static FpL load_const(const uint32_t *c) {
+        const bool hi = hi_lane();
+        FpL r;
+#pragma unroll
+        for (int j = 0; j < H; j++) r.l[j] = hi ? c[H + j] : c[j];
+        return r;
+    }
+    PTAU_HD static FpL zero() {
+        FpL r;
+#pragma unroll
+        for (int j = 0; j < H; j++) r.l[j] = 0;
+        return r;
+    }
+    PTAU_HD static FpL one() { return load_const(P::R1); }
+    PTAU_HD static bool both(bool mine) {
+        const uint32_t theirs = lane_xchg(mine ? 1u : 0u);
+        return mine && theirs != 0u;
+    }
+    PTAU_HD bool is_zero() const {
+        uint32_t o = 0;
+#pragma unroll
+        for (int j = 0; j < H; j++) o |= l[j];
+        return both(o == 0);
+    }
+    PTAU_HD bool operator==(const FpL &b) const {
+        uint32_t o = 0;
+#pragma unroll
+        for (int j = 0; j < H; j++) o |= l[j] ^ b.l[j];
+        return both(o == 0);
+    }
+    PTAU_HD bool operator!=(const FpL &b) const { return !(*this == b); }
+
+    // the element in one lane (both lanes get all N limbs) and back
+    PTAU_HD Full gather() const {
+        const bool hi = hi_lane();
+        Full f;
+#pragma unroll
+        for (int j = 0; j < H; j++) {
+            const uint32_t o = lane_xchg(l[j]);
+            f.l[j] = hi ? o : l[j];
+            f.l[H + j] = hi ? l[j] : o;
+        }
+        return f;
+    }
+    PTAU_HD static FpL scatter(const Full &f) {
+        const bool hi = hi_lane();
+        FpL r;
+#pragma unroll
+        for (int j = 0; j < H; j++) r.l[j] = hi ? f.l[H + j] : f.l[j];
+        return r;
+    }
+
+    // ---- carry plumbing between the two lanes of a pair ----
+    // Fold a carry (or borrow: signed) that arrived from the even lane into the odd lane's digits d[0..H): d[0] += cin, with
+    // the ripple beyond d[0] on a lane-local slow path.  Returns the carry out of the top digit (0 almost always).
+    PTAU_HD static int32_t fold_carry(uint32_t (&d)[H], int32_t cin) {
+        int32_t v = (int32_t)d[0] + cin;
+        int32_t c = v >> LB;
+        d[0] = (uint32_t)v & MASK;
+        if (c != 0) {   // |cin| <= 1 moved d[0] across a limb boundary: probability 2^-29 per operation, no cross-lane move inside
+#pragma unroll
+            for (int j = 1; j < H; j++) {
+                v = (int32_t)d[j] + c;
+                c = v >> LB;
+                d[j] = (uint32_t)v & MASK;
+            }
+        }
+        return c;
+    }
+
+    // a + b mod p
+    PTAU_HD static FpL add(const FpL &a, const FpL &b) {
+        const bool hi = hi_lane();
+        uint32_t d[H], s[H];
+        int32_t cy = 0;
+        uint32_t c2 = 0;
+#pragma unroll
+        for (int j = 0; j < H; j++) {
+            const uint32_t ab = a.l[j] + b.l[j];                                   // < 2^30
+            const uint32_t pj = hi ? P::MOD[H + j] : P::MOD[j];
+            const int32_t v = (int32_t)ab - (int32_t)pj + cy;
+            cy = v >> LB;
+            d[j] = (uint32_t)v & MASK;
+            const uint32_t w = ab + c2;
+            c2 = w >> LB;
+            s[j] = w & MASK;
+        }
+        // the even lane's carry-outs enter the odd lane's chains
+        const int32_t cy_in = (int32_t)lane_xchg((uint32_t)cy);
+        const int32_t c2_in = (int32_t)lane_xchg(c2);
+        const int32_t top = cy + fold_carry(d, hi ? cy_in : 0);    // odd lane: the borrow of the whole a + b - p
+        (void)fold_carry(s, hi ? c2_in : 0);
+        const int32_t top_o = (int32_t)lane_xchg((uint32_t)top);
+        const bool borrow = (hi ? top : top_o) < 0;                 // a + b < p: keep the sum
+        FpL r;
+#pragma unroll
+        for (int j = 0; j < H; j++) r.l[j] = borrow ? s[j] : d[j];
+        return r;
+    }
+    PTAU_HD static FpL sub(const FpL &a, const FpL &b) {
+        const bool hi = hi_lane();
+        uint32_t d[H];
+        int32_t cy = 0;
+#pragma unroll
+        for (int j = 0; j < H; j++) {
+            const int32_t v = (int32_t)a.l[j] - (int32_t)b.l[j] + cy;
+            cy = v >> LB;
+            d[j] = (uint32_t)v & MASK;
+        }
+        const int32_t cy_in = (int32_t)lane_xchg((uint32_t)cy);
+        const int32_t top = cy + fold_carry(d, hi ? cy_in : 0);
+        const int32_t top_o = (int32_t)lane_xchg((uint32_t)top);
+        const uint32_t mask = (hi ? top : top_o) < 0 ? 0xffffffffu : 0u;   // negative: add p (mod 2^(29 N))
+        uint32_t c2 = 0;
+        uint32_t r[H];
+#pragma unroll
+        for (int j = 0; j < H; j++) {
+            const uint32_t pj = hi ? P::MOD[H + j] : P::MOD[j];
+            const uint32_t w = d[j] + (pj & mask) + c2;
+            c2 = w >> LB;
+            r[j] = w & MASK;
+        }
+        const int32_t c2_in = (int32_t)lane_xchg(c2);
+        (void)fold_carry(r, hi ? c2_in : 0);
+        FpL o;
+#pragma unroll
+        for (int j = 0; j < H; j++) o.l[j] = r[j];
+        return o;
+    }
+    PTAU_HD static FpL neg(const FpL &a) {
+        const bool hi = hi_lane();
+        const uint32_t nz = a.is_zero() ? 0u : 0xffffffffu;
+        uint32_t d[H];
+        int32_t cy = 0;
+#pragma unroll
+        for (int j = 0; j < H; j++) {
+            const uint32_t pj = hi ? P::MOD[H + j] : P::MOD[j];
+            const int32_t v = (int32_t)(pj & nz) - (int32_t)a.l[j] + cy;
+            cy = v >> LB;
+            d[j] = (uint32_t)v & MASK;
+        }
+        const int32_t cy_in = (int32_t)lane_xchg((uint32_t)cy);
+        (void)fold_carry(d, hi ? cy_in : 0);
+        FpL r;
+#pragma unroll
+        for (int j = 0; j < H; j++) r.l[j] = d[j];
+        return r;
+    }
+    PTAU_HD static FpL dbl(const FpL &a) { return add(a, a); }
+
+    // ---- Montgomery product, accumulator row distributed over the pair (see the header comment) ----
+    typedef uint32_t VecH __attribute__((ext_vector_type(H)));
+    PTAU_HD static void row_mul(const uint32_t (&a)[H], const uint32_t (&b)[H], uint32_t (&out)[H]) {
+        const bool hi = hi_lane();
+        uint32_t pm[H];
+#pragma unroll
+        for (int j = 0; j < H; j++) pm[j] = hi ? P::MOD[H + j] : P::MOD[j];
+        uint64_t acc[H];
+#pragma unroll
+        for (int j = 0; j < H; j++) acc[j] = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            // limb i of a in both lanes: one DPP broadcast from the lane that holds it
+            const uint32_t ai = i < H ? lane_bcast_even(a[i]) : lane_bcast_odd(a[i - H]);
+#pragma unroll
+            for (int j = 0; j < H; j++) mac64_vv(acc[j], ai, b[j]);
+            // m from the even lane's position 0, broadcast to the pair
+            const uint32_t m = lane_bcast_even(((uint32_t)acc[0] * P::INV) & MASK);
+#pragma unroll
+            for (int j = 0; j < H; j++) mac64_vv(acc[j], m, pm[j]);
+            // Shift the row down one limb, the same code in both lanes: the lowest accumulator leaves its carry to the next
+            // one and its low 29 bits to the partner, whose top slot they become.  Even lane: those bits are zero by the
+            // choice of m, so the odd lane's top slot restarts at zero; odd lane: they are limb H of the row and arrive as
+            // the even lane's new top slot.
+            const uint64_t x = acc[0];
+            const uint32_t recv = lane_xchg((uint32_t)x & MASK);
+#pragma unroll
+            for (int j = 0; j + 1 < H; j++) acc[j] = acc[j + 1];
+            acc[0] += x >> LB;
+            acc[H - 1] = recv;
+        }
+        // carry-propagate both halves at once (carry-in 0), then fold the even lane's carry-out (< 2^36) into the odd
+        // lane's two lowest digits
+        uint32_t r[H];
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < H; j++) {
+            const uint64_t v = acc[j] + c;
+            r[j] = (uint32_t)v & MASK;
+            c = v >> LB;
+        }
+        {
+            const uint32_t clo = lane_xchg((uint32_t)c & MASK), chi = lane_xchg((uint32_t)(c >> LB));
+            const uint32_t w0 = r[0] + (hi ? clo : 0u);
+            r[0] = w0 & MASK;
+            const uint32_t w1 = r[1] + (hi ? chi : 0u) + (w0 >> LB);
+            r[1] = w1 & MASK;
+            uint32_t cc = w1 >> LB;
+            if (cc) {   // rare: lane-local ripple
+#pragma unroll
+                for (int j = 2; j < H; j++) {
+                    const uint32_t w = r[j] + cc;
+                    r[j] = w & MASK;
+                    cc = w >> LB;
+                }
+            }
+        }
+        // result < 2p: one conditional subtraction
+        uint32_t d[H];
+        int32_t cy = 0;
+#pragma unroll
+        for (int j = 0; j < H; j++) {
+            const int32_t v = (int32_t)r[j] - (int32_t)pm[j] + cy;
+            cy = v >> LB;
+            d[j] = (uint32_t)v & MASK;
+        }
+        const int32_t cy_in = (int32_t)lane_xchg((uint32_t)cy);
+        const int32_t top = cy + fold_carry(d, hi ? cy_in : 0);
+        const int32_t top_o = (int32_t)lane_xchg((uint32_t)top);
+        const bool borrow = (hi ? top : top_o) < 0;
+#pragma unroll
+        for (int j = 0; j < H; j++) out[j] = borrow ? r[j] : d[j];
+    }
+    // one out-of-line copy per field, register ABI (H limbs per operand in VGPRs)
+    __device__ __noinline__ static VecH mul_vec(VecH a, VecH b) {
+        uint32_t x[H], y[H], r[H];
+#pragma unroll
+        for (int j = 0; j < H; j++) { x[j] = a[j]; y[j] = b[j]; }
+        row_mul(x, y, r);
+        VecH o;
+#pragma unroll
+        for (int j = 0; j < H; j++) o[j] = r[j];
+        return o;
+    }
+    PTAU_HD static FpL mul(const FpL &a, const FpL &b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        VecH x, y;
+#pragma unroll
+        for (int j = 0; j < H; j++) { x[j] = a.l[j]; y[j] = b.l[j]; }
+        const VecH o = mul_vec(x, y);
+        FpL r;
+#pragma unroll
+        for (int j = 0; j < H; j++) r.l[j] = o[j];
+        return r;
+#else
+        (void)b;
+        return a;   // lane-split fields exist on the device only
+#endif
+    }
+    PTAU_HD static FpL sqr(const FpL &a) { return mul(a, a); }
+
+    PTAU_HD static FpL mul_small(const FpL &a, int k) {
+        if (k == 0) return zero();
+        bool ng = k < 0;
+        unsigned uk = ng ? (unsigned)(-k) : (unsigned)k;
+        FpL acc = zero(), base = a;
+        bool first = true;
+        while (uk) {
+            if (uk & 1u) { acc = first ? base : add(acc, base); first = false; }
+            uk >>= 1;
+            if (uk) base = dbl(base);
+        }
+        return ng ? neg(acc) : acc;
+    }
+
+    // canonical value as N limbs of 29 bits (the same pointer in both lanes)
+    PTAU_HD static FpL from_canonical(const uint32_t *c) { return mul(load_const(c), load_const(P::R2)); }
+    PTAU_HD void to_canonical(uint32_t *c) const {
+        uint32_t one_raw[N];
+#pragma unroll
+        for (int i = 0; i < N; i++) one_raw[i] = i == 0 ? 1u : 0u;
+        const Full f = mul(*this, load_const(one_raw)).gather();
+#pragma unroll
+        for (int i = 0; i < N; i++) c[i] = f.l[i];
+    }
+    // off the hot path: the single-lane code, run redundantly by both lanes
+    PTAU_HD static FpL inverse(const FpL &a) { return scatter(Full::inverse(a.gather())); }
+    PTAU_HD static bool sqrt_ex(const FpL &a, FpL &out, FpL *inv_out) {
+        Full o, io;
+        const bool ok = Full::sqrt_ex(a.gather(), o, inv_out ? &io : nullptr);
+        out = scatter(o);
+        if (inv_out) *inv_out = scatter(io);
+        return ok;
+    }
+    PTAU_HD static bool sqrt(const FpL &a, FpL &out) { return sqrt_ex(a, out, nullptr); }
+    PTAU_HD static bool read_bytes(const uint8_t *in, bool with_flags, uint8_t *flags, FpL &out) {
+        Full f;
+        const bool ok = Full::read_bytes(in, with_flags, flags, f);   // both lanes read the same bytes
+        out = scatter(f);
+        return ok;
+    }
+    PTAU_HD void write_bytes(uint8_t *out, uint8_t flags) const {
+        const Full f = gather();
+        if (!hi_lane()) f.write_bytes(out, flags);
+    }
+    PTAU_HD int sign_class() const { return gather().sign_class(); }
+};
+
+}  // namespace ptau

@@ -19,7 +19,10 @@ BLS_G2_B1 = 15519865560778145640639164021693612012183610765294879632393055760003
 # Base fields whose curves use the reduced-radix (2^29) field class.  Measured (MI355X, updates/s, 32-bit -> 29-bit limbs):
 # BLS12-377 G1 26.1 M -> 31.4 M, G2 6.7 M -> 7.6 M; MNT4 G1 (2^18) 1.07 M -> 1.11 M; MNT6 G2 86.6 k -> 96.6 k;
 # BW6-761 (2^18) 3.19 M -> 3.05 M — its 27-limb products go by reference through memory and are not MAC-bound, so it stays on 32.
-RADIX29 = {"BlsFq", "Mnt4Fq", "Mnt6Fq"}
+RADIX29 = {"BlsFq", "Mnt4Fq", "Mnt6Fq", "Bw6Fq"}
+# BW6-761 (round 2): 28 limbs of 29 bits — one more than ceil(761 / 29) — so that the element splits evenly over a lane pair
+# (fpl.hpp); its single-lane kernels (verify path) use the same representation so both kinds of kernel exchange values limb for limb.
+RADIX29_LIMBS = {"Bw6Fq": 28}
 
 
 # The MNT twists' G2 generators are NOT here: ark-mnt4-753 / ark-mnt6-753's constants are not recoverable offline, so the
@@ -116,13 +119,14 @@ def limbs(x, n, lb=None):
     return ", ".join("0x%08xu" % ((x >> (lb * i)) & ((1 << lb) - 1)) for i in range(n))
 
 
-def field(name, p, cubic_nr=None, sqrt_tables=False, lb=32):
+def field(name, p, cubic_nr=None, sqrt_tables=False, lb=32, n_limbs=None):
     """Parameter struct of one prime field.  lb = 32: full 32-bit limbs (Fp, fp.hpp).  lb = 29: reduced radix (Fp29,
     fp29.hpp): ceil(bits/29) limbs of 29 bits, R = 2^(29 N), so that the 2N products of a product-scanning column fit a
     64-bit accumulator and the multiply-accumulate needs no carry instruction.  Exponents and the *32 arrays stay packed."""
     global _LB
     _LB = lb
-    n = (p.bit_length() + lb - 1) // lb
+    n = n_limbs or (p.bit_length() + lb - 1) // lb
+    assert lb * n >= p.bit_length()
     n32 = (p.bit_length() + 31) // 32
     R = 1 << (lb * n)
     inv = (-pow(p, -1, 1 << lb)) % (1 << lb)
@@ -209,7 +213,8 @@ def main():
     # SCALAR fields of BW6-761 / MNT6 / MNT4, and scalars are consumed as packed 32-bit words)
     for name, p in (("BlsFq", BLS_Q), ("Bw6Fq", BW6_Q), ("Mnt4Fq", MNT_A), ("Mnt6Fq", MNT_B)):
         if name in RADIX29:
-            txt, n, R = field(name + "R29", p, cubic_nr=11 if name == "Mnt6Fq" else None, sqrt_tables=True, lb=29)
+            txt, n, R = field(name + "R29", p, cubic_nr=11 if name == "Mnt6Fq" else None, sqrt_tables=True, lb=29,
+                              n_limbs=RADIX29_LIMBS.get(name))
             fields[name + "R29"] = (p, n, R, 29)
             out.append(txt)
     fq_of = lambda base: base + "R29" if base in RADIX29 else base   # the struct a curve over `base` is generated for

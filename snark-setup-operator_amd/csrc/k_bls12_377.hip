@@ -4,7 +4,7 @@
 namespace ptau {
 using G1T = GroupTypes<BlsFqR29, BlsFr, BlsG1Cfg>;
 using G2T = GroupTypes<BlsFqR29, BlsFr, BlsG2Cfg>;
-using G2L = GroupTypes<BlsFqR29, BlsFr, BlsG2Cfg, true>;   // Fq2 over lane pairs (tau-update of uncompressed points)
+using G2L = GroupTypes<BlsFqR29, BlsFr, BlsG2Cfg, LANES_FQ2_PAIR>;   // Fq2 over lane pairs (tau-update of uncompressed points)
 
 const GroupOps *ops_bls12_377(int group) {
     static const GroupOps o1 = Launch<G1T>::ops();

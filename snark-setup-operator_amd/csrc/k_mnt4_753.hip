@@ -4,12 +4,13 @@
 namespace ptau {
 using G1T = GroupTypes<Mnt4FqR29, Mnt4Fr, Mnt4G1Cfg>;
 using G2T = GroupTypes<Mnt4FqR29, Mnt4Fr, Mnt4G2Cfg>;
-// (a lane-pair twin of G2T measured SLOWER here — 138 k vs 217 k updates/s: the 24-limb base products go by reference
-// through memory, so halving the register footprint buys nothing and schoolbook costs 4/3 of Karatsuba)
+// tau-update twins: every 26-limb base-field element over a lane pair (fpl.hpp)
+using G1S = GroupTypes<Mnt4FqR29, Mnt4Fr, Mnt4G1Cfg, LANES_LIMB_SPLIT>;
+using G2S = GroupTypes<Mnt4FqR29, Mnt4Fr, Mnt4G2Cfg, LANES_LIMB_SPLIT>;
 
 const GroupOps *ops_mnt4_753(int group) {
-    static const GroupOps o1 = Launch<G1T>::ops();
-    static const GroupOps o2 = Launch<G2T>::ops();
+    static const GroupOps o1 = Launch<G1T, G1S>::ops();
+    static const GroupOps o2 = Launch<G2T, G2S>::ops();
     return group == 1 ? &o1 : (group == 2 ? &o2 : nullptr);
 }
 }  // namespace ptau

@@ -4,10 +4,13 @@
 namespace ptau {
 using G1T = GroupTypes<Mnt6FqR29, Mnt6Fr, Mnt6G1Cfg>;
 using G2T = GroupTypes<Mnt6FqR29, Mnt6Fr, Mnt6G2Cfg>;
+// tau-update twins: every 26-limb base-field element over a lane pair (fpl.hpp)
+using G1S = GroupTypes<Mnt6FqR29, Mnt6Fr, Mnt6G1Cfg, LANES_LIMB_SPLIT>;
+using G2S = GroupTypes<Mnt6FqR29, Mnt6Fr, Mnt6G2Cfg, LANES_LIMB_SPLIT>;
 
 const GroupOps *ops_mnt6_753(int group) {
-    static const GroupOps o1 = Launch<G1T>::ops();
-    static const GroupOps o2 = Launch<G2T>::ops();
+    static const GroupOps o1 = Launch<G1T, G1S>::ops();
+    static const GroupOps o2 = Launch<G2T, G2S>::ops();
     return group == 1 ? &o1 : (group == 2 ? &o2 : nullptr);
 }
 }  // namespace ptau

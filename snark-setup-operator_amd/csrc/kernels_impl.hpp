@@ -37,6 +37,9 @@
 #ifndef PTAU_MIN_WAVES_WIDE
 #define PTAU_MIN_WAVES_WIDE 2
 #endif
+#ifndef PTAU_SPLIT_MIN_WAVES
+#define PTAU_SPLIT_MIN_WAVES 2   // limb-split (FpL) kernels: waves per SIMD they are compiled for
+#endif
 
 namespace ptau {
 
@@ -45,14 +48,20 @@ enum : int { ERRBIT_NONCANONICAL = 1, ERRBIT_NOT_ON_CURVE = 2, ERRBIT_INFINITY =
 
 constexpr int SCALAR_TABLE_ENTRIES = 64;   // tau^(2^k), k < 64, preceded by the base coefficient
 
+// How a point is laid over the lanes of a wavefront: one lane per point; an Fq2 element over a lane pair, one coefficient
+// per lane (Fp2L, ext.hpp: BLS12-377 G2); every base-field element over a lane pair, half of the limbs per lane (FpL,
+// fpl.hpp: the 26-28-limb fields of MNT4/MNT6-753 and BW6-761).  The last two run two threads per point.
+enum : int { LANES_ONE = 0, LANES_FQ2_PAIR = 1, LANES_LIMB_SPLIT = 2 };
+
 // Host+device view of one group's types.
-template <class FqP, class FrP, class Cfg, bool LANE_PAIR = false>
+template <class FqP, class FrP, class Cfg, int LANE_MODE_ = LANES_ONE>
 struct GroupTypes {
-    using Fq = FieldOf<FqP>;   // Fp (32-bit limbs) or Fp29 (29-bit limbs), as the parameter struct was generated
+    static constexpr int LANE_MODE = LANE_MODE_;
+    // Fp (32-bit limbs) or Fp29 (29-bit limbs), as the parameter struct was generated; FpL: the Fp29 element over two lanes
+    using Fq = std::conditional_t<LANE_MODE == LANES_LIMB_SPLIT, FpL<FqP>, FieldOf<FqP>>;
     using Fr = Fp<FrP>;        // scalars are consumed as packed 32-bit words
-    // LANE_PAIR: an Fq2 element spread over two adjacent lanes (Fp2L, ext.hpp) — two threads per point
     using F = std::conditional_t<Cfg::DEG == 1, Fq,
-              std::conditional_t<Cfg::DEG == 2, std::conditional_t<LANE_PAIR, Fp2L<Fq, Cfg::NR>, Fp2<Fq, Cfg::NR>>,
+              std::conditional_t<Cfg::DEG == 2, std::conditional_t<LANE_MODE == LANES_FQ2_PAIR, Fp2L<Fq, Cfg::NR>, Fp2<Fq, Cfg::NR>>,
                                  Fp3<Fq, Cfg::NR>>>;
     static constexpr int LPP = F::LANES;   // lanes (threads) per point
     using J = Jac<F, Cfg>;
@@ -67,7 +76,7 @@ struct GroupTypes {
     // otherwise) is what gets BW6-761 and MNT G1 to two waves.
     static constexpr bool SMALL = F::DEG == 1 && F::POINT_OPS_INLINE;   // a point operation inlines at <= 256 registers
     static constexpr int K1_MIN_WAVES = (LPP == 1 && SMALL) ? PTAU_K1_G1_MIN_WAVES : 0;   // 0: same as MIN_WAVES
-    static constexpr int MIN_WAVES = LPP == 2 ? PTAU_LANE_MIN_WAVES : SMALL ? PTAU_G1_MIN_WAVES : (PTAU_MIN_WAVES_WIDE > 0 ? PTAU_MIN_WAVES_WIDE : 1);
+    static constexpr int MIN_WAVES = LANE_MODE == LANES_LIMB_SPLIT ? PTAU_SPLIT_MIN_WAVES : LPP == 2 ? PTAU_LANE_MIN_WAVES : SMALL ? PTAU_G1_MIN_WAVES : (PTAU_MIN_WAVES_WIDE > 0 ? PTAU_MIN_WAVES_WIDE : 1);
 };
 
 // table layout: [0] = base coefficient c*tau^start, [1+k] = tau^(2^k); all Montgomery, Fr::N limbs
@@ -383,7 +392,24 @@ constexpr int WINDOW_ENTRIES = 8;
 // so normalize_kernel of the single-lane group type reads what a lane-pair kernel wrote.
 template <class G>
 PTAU_HD void store_jac(typename G::J *scratch, uint64_t i, const typename G::J &v) {
-    if constexpr (G::LPP == 2) {
+    if constexpr (G::LANE_MODE == LANES_LIMB_SPLIT) {
+        // every base-field coefficient in turn, this lane's H limbs at their place among the N of the single-lane element
+        using L = typename G::Fq;
+        constexpr int D = G::F::DEG;
+        uint32_t *dst = reinterpret_cast<uint32_t *>(scratch) + i * (uint64_t)(3 * D * L::N) + (lane_parity() ? L::H : 0);
+        auto put = [&](const L &c, int slot) {
+#pragma unroll
+            for (int j = 0; j < L::H; j++) dst[slot * L::N + j] = c.l[j];
+        };
+        auto put_f = [&](const typename G::F &f, int slot) {
+            if constexpr (D == 1) put(f, slot);
+            else if constexpr (D == 2) { put(f.c0, slot); put(f.c1, slot + 1); }
+            else { put(f.c0, slot); put(f.c1, slot + 1); put(f.c2, slot + 2); }
+        };
+        put_f(v.X, 0);
+        put_f(v.Y, D);
+        put_f(v.Z, 2 * D);
+    } else if constexpr (G::LPP == 2) {
         typename G::Fq *base = reinterpret_cast<typename G::Fq *>(scratch) + i * 6 + lane_parity();
         base[0] = v.X.c;
         base[2] = v.Y.c;
@@ -437,9 +463,7 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
 #pragma unroll
                 for (int j = 0; j < HL; j++) kk[h][j] = addc(kk[h][j], 0x88888888u, c2);   // halves < 2^(32 HL - 1): no carry out
             }
-            F beta;
-#pragma unroll
-            for (int j = 0; j < F::N; j++) beta.l[j] = Cfg::GLV_BETA[j];
+            const F beta = F::load_const(Cfg::GLV_BETA);
             J acc = J::infinity();
             for (int w = HL * 8 - 1; w >= 0; w--) {
                 if (!acc.is_inf()) {
@@ -1044,7 +1068,13 @@ inline bool lane_pair_enabled() {
     return v;
 }
 
-// GL: the lane-pair twin of G (same curve, Fq2 elements over two lanes) or void.
+// GL: the two-threads-per-point twin of G (same curve and byte formats) or void: an Fq2-pair twin serves the tau-update, the
+// membership test and the bucket sums of uncompressed points; a limb-split twin serves the tau-update (K1).
+template <class GL, int MODE>
+constexpr bool twin_is() {
+    if constexpr (std::is_void_v<GL>) return false;
+    else return GL::LANE_MODE == MODE;
+}
 template <class G, class GL = void>
 struct Launch {
     using Fr = typename G::Fr;
@@ -1107,7 +1137,7 @@ struct Launch {
     }
     static void msm_accumulate(hipStream_t s, const void *aff, const uint32_t *sorted, const uint32_t *offsets,
                                const uint32_t *run_offsets, void *partials, uint32_t shift, uint32_t total_buckets, uint64_t max_runs) {
-        if constexpr (!std::is_void_v<GL>) {
+        if constexpr (twin_is<GL, LANES_FQ2_PAIR>()) {
             if (lane_pair_enabled()) {   // two threads per run; affine input and Jacobian partials in G's layouts
                 hipLaunchKernelGGL(msm_accumulate_kernel<GL>, grid(max_runs * 2), dim3(256), 0, s, (const typename GL::A *)aff,
                                    sorted, offsets, run_offsets, (typename GL::J *)partials, shift, total_buckets);
@@ -1151,7 +1181,7 @@ struct Launch {
     static void endo_subgroup(hipStream_t s, const uint8_t *in, int cin, uint64_t n, int *err) {
         if constexpr (G::J::CfgT::ENDO_KIND != 0) {
             if (!n) return;
-            if constexpr (!std::is_void_v<GL>) {
+            if constexpr (twin_is<GL, LANES_FQ2_PAIR>()) {
                 if (!cin && lane_pair_enabled()) {
                     hipLaunchKernelGGL((endo_subgroup_kernel<GL, 0>), grid(n * 2), dim3(256), 0, s, in, n, err);
                     return;

@@ -276,7 +276,7 @@ struct KeyGen {
 };
 
 using BlsK = KeyGen<GroupTypes<BlsFqR29, BlsFr, BlsG1Cfg>, GroupTypes<BlsFqR29, BlsFr, BlsG2Cfg>>;
-using Bw6K = KeyGen<GroupTypes<Bw6Fq, Bw6Fr, Bw6G1Cfg>, GroupTypes<Bw6Fq, Bw6Fr, Bw6G2Cfg>>;
+using Bw6K = KeyGen<GroupTypes<Bw6FqR29, Bw6Fr, Bw6G1Cfg>, GroupTypes<Bw6FqR29, Bw6Fr, Bw6G2Cfg>>;
 using Mnt4K = KeyGen<GroupTypes<Mnt4FqR29, Mnt4Fr, Mnt4G1Cfg>, GroupTypes<Mnt4FqR29, Mnt4Fr, Mnt4G2Cfg>>;
 using Mnt6K = KeyGen<GroupTypes<Mnt6FqR29, Mnt6Fr, Mnt6G1Cfg>, GroupTypes<Mnt6FqR29, Mnt6Fr, Mnt6G2Cfg>>;
 

@@ -158,7 +158,7 @@ int main(int argc, char **argv) {
     int cin = atoi(argv[6]), cout = atoi(argv[7]);
     switch (curve) {
     case 0: DISPATCH(BlsFqR29, BlsFr, BlsG1Cfg, BlsG2Cfg)
-    case 1: DISPATCH(Bw6Fq, Bw6Fr, Bw6G1Cfg, Bw6G2Cfg)
+    case 1: DISPATCH(Bw6FqR29, Bw6Fr, Bw6G1Cfg, Bw6G2Cfg)
     case 2: DISPATCH(Mnt4FqR29, Mnt4Fr, Mnt4G1Cfg, Mnt4G2Cfg)
     case 3: DISPATCH(Mnt6FqR29, Mnt6Fr, Mnt6G1Cfg, Mnt6G2Cfg)
     }
