@@ -204,10 +204,21 @@ int ptau_power_pairs(int curve, int group, const uint8_t *in, int compressed_in,
 
 /* setup_utils::check_same_ratio((a, b), (c, d)) — e(a, d) == e(b, c) — reference call sites
  * src/bin/verify_transcript.rs:812-822, src/bin/control.rs:587-591 (inside transform_ratios / verification).
- * a, b: G1 points, c, d: G2 points, all UNCOMPRESSED.  The O(1) pairing tail runs on the host CPU.
+ * a, b: G1 points, c, d: G2 points, all UNCOMPRESSED.  This single-check form runs on the HOST CPU (it needs no GPU: the
+ * checker of the GPU kernel in the tests, and the standalone ptau_verify_pok); the verification entry points use the batch form.
  * Returns PTAU_OK when the ratios agree, PTAU_E_INVALID_RATIO when they do not. */
 int ptau_check_same_ratio(int curve, const uint8_t *g1_a, const uint8_t *g1_b, const uint8_t *g2_c,
                           const uint8_t *g2_d, char *err, size_t err_len);
+
+/* setup_utils::check_same_ratio for n independent checks in ONE launch of the pairing kernel (K5 on the GPU: Miller loop and
+ * final exponentiation in HIP, an Fq^k element spread over k lanes, one workgroup per check) — what the verification entry
+ * points use for the proofs of knowledge, the chunk-0 before/after checks and the power-ratio checks (reference call sites
+ * src/bin/verify_transcript.rs:812-822, src/bin/control.rs:587-591, src/bin/contribute.rs:968-986).
+ * checks = n x (g1_a | g1_b | g2_c | g2_d), UNCOMPRESSED; results[i] = 1 same ratio, 0 different, -1 malformed point.
+ * gt_out (optional, test hook): per check the reduced pairing product e(a, d) * e(-b, c) as k x ceil(bits(q)/32) canonical
+ * little-endian 32-bit words (coefficients of w^0 .. w^(k-1) in Fq[w]/(w^k - nu)); the value 1 <=> same ratio. */
+int ptau_check_same_ratio_batch(int curve, const uint8_t *checks, uint64_t n, int *results, uint32_t *gt_out, int device,
+                                char *err, size_t err_len);
 
 /* Phase1::initialization via phase1_cli::new_challenge (src/bin/new_setup.rs:105-109, verify_transcript.rs:322-326):
  * blank BLAKE2b hash, then every element = the group generator, uncompressed (host only, no GPU needed).

@@ -24,6 +24,7 @@
 
 #include "../../include/ptau.h"
 #include "kernels_impl.hpp"
+#include "pairing_dev.hpp"
 #include "pairing_host.hpp"
 
 namespace {
@@ -50,6 +51,16 @@ const GroupOps *get_ops(int curve, int group) {
     case PTAU_CURVE_BW6_761: return ptau::ops_bw6_761(group);
     case PTAU_CURVE_MNT4_753: return ptau::ops_mnt4_753(group);
     case PTAU_CURVE_MNT6_753: return ptau::ops_mnt6_753(group);
+    }
+    return nullptr;
+}
+
+const ptau::PairingOps *get_pairing_ops(int curve) {
+    switch (curve) {
+    case PTAU_CURVE_BLS12_377: return ptau::pairing_ops_bls12_377();
+    case PTAU_CURVE_BW6_761: return ptau::pairing_ops_bw6_761();
+    case PTAU_CURVE_MNT4_753: return ptau::pairing_ops_mnt4_753();
+    case PTAU_CURVE_MNT6_753: return ptau::pairing_ops_mnt6_753();
     }
     return nullptr;
 }
@@ -102,6 +113,8 @@ struct DeviceCtx {
     void *d_small = nullptr;                  // single-point results (MSM)
     void *msm_ws = nullptr;                   // bucket-MSM workspace
     size_t msm_cap = 0;
+    void *d_pair = nullptr;                   // pairing kernel: packed checks | results | GT values
+    size_t pair_cap = 0;
     size_t in_cap = 0, out_cap = 0;
     // side stream for the lone beta_g2 element of a chunk: its membership test is ONE thread's scalar multiplication
     // (~170 ms of latency on MNT4 G2, ~370 ms on MNT6 G2) and runs beside the vectors instead of after them
@@ -1150,18 +1163,37 @@ struct RatioJob {
     const uint8_t *a, *b, *c2, *d2;   // (a, b) in G1, (c2, d2) in G2, all uncompressed
     std::string what;                  // message when the ratios differ
 };
-int run_ratio_jobs(int curve, const std::vector<RatioJob> &jobs, const Err &err) {
-    std::vector<std::future<int>> futs;
-    for (auto &j : jobs)
-        futs.push_back(std::async(std::launch::async, [curve, &j] { return ptau_check_same_ratio(curve, j.a, j.b, j.c2, j.d2, nullptr, 0); }));
-    int bad_rc = PTAU_OK;
-    size_t bad = 0;
-    for (size_t i = 0; i < futs.size(); i++) {
-        const int r = futs[i].get();
-        if (r && !bad_rc) { bad_rc = r; bad = i; }
+// device >= 0: ONE launch of the pairing kernel, a workgroup per job (ptau_check_same_ratio_batch); device < 0: the host
+// tail, one host thread per job (the standalone ptau_verify_pok / ptau_check_same_ratio, which need no GPU).
+int run_ratio_jobs(int curve, const std::vector<RatioJob> &jobs, const Err &err, int device = -1) {
+    if (jobs.empty()) return PTAU_OK;
+    std::vector<int> res(jobs.size(), 0);
+    if (device >= 0) {
+        const ptau::PairingOps *po = get_pairing_ops(curve);
+        const GroupOps *g1 = get_ops(curve, 1), *g2 = get_ops(curve, 2);
+        std::vector<uint8_t> packed(jobs.size() * po->check_bytes);
+        for (size_t i = 0; i < jobs.size(); i++) {
+            uint8_t *q = packed.data() + i * po->check_bytes;
+            memcpy(q, jobs[i].a, g1->uncomp);
+            memcpy(q + g1->uncomp, jobs[i].b, g1->uncomp);
+            memcpy(q + 2 * (size_t)g1->uncomp, jobs[i].c2, g2->uncomp);
+            memcpy(q + 2 * (size_t)g1->uncomp + g2->uncomp, jobs[i].d2, g2->uncomp);
+        }
+        int rc = ptau_check_same_ratio_batch(curve, packed.data(), jobs.size(), res.data(), nullptr, device, err.buf, err.len);
+        if (rc) return rc;
+    } else {
+        std::vector<std::future<int>> futs;
+        for (auto &j : jobs)
+            futs.push_back(std::async(std::launch::async, [curve, &j] {
+                const int r = ptau_check_same_ratio(curve, j.a, j.b, j.c2, j.d2, nullptr, 0);
+                return r == PTAU_OK ? 1 : (r == PTAU_E_INVALID_RATIO ? 0 : -1);
+            }));
+        for (size_t i = 0; i < futs.size(); i++) res[i] = futs[i].get();
     }
-    if (bad_rc == PTAU_E_INVALID_RATIO) return err.fail(bad_rc, "%s", jobs[bad].what.c_str());
-    if (bad_rc) return err.fail(bad_rc, "malformed point in the same-ratio check: %s", jobs[bad].what.c_str());
+    for (size_t i = 0; i < jobs.size(); i++) {   // the first failure in job order, whatever the execution order was
+        if (res[i] == 0) return err.fail(PTAU_E_INVALID_RATIO, "%s", jobs[i].what.c_str());
+        if (res[i] < 0) return err.fail(PTAU_E_POINT, "malformed point in the same-ratio check: %s", jobs[i].what.c_str());
+    }
     return PTAU_OK;
 }
 
@@ -1365,8 +1397,8 @@ int verify_chunk_impl(const ptau_params *p, const uint8_t *challenge, size_t cha
     // the power-ratio pairings start at once; the proofs of knowledge are bound to BLAKE2b(challenge) and wait for it
     char ratio_msg[256] = {0};
     const int curve_id = p->curve;
-    auto fut_ratio = std::async(std::launch::async, [&ratio_jobs, &ratio_msg, curve_id] {
-        return run_ratio_jobs(curve_id, ratio_jobs, Err{ratio_msg, sizeof(ratio_msg)});
+    auto fut_ratio = std::async(std::launch::async, [&ratio_jobs, &ratio_msg, curve_id, device] {
+        return run_ratio_jobs(curve_id, ratio_jobs, Err{ratio_msg, sizeof(ratio_msg)}, device);
     });
     struct RatioJoin {   // the pairing threads read `pairs` and the caller's buffers
         std::future<int> &f;
@@ -1382,7 +1414,7 @@ int verify_chunk_impl(const ptau_params *p, const uint8_t *challenge, size_t cha
             g2_s = g2_s_own.data();
         }
         if ((rc = collect_pok_jobs(p, sz, challenge, response, g2_s, pok_scratch, pok_jobs, err))) return rc;
-        if ((rc = run_ratio_jobs(p->curve, pok_jobs, err))) return rc;
+        if ((rc = run_ratio_jobs(p->curve, pok_jobs, err, device))) return rc;
     }
     if ((rc = fut_ratio.get())) return err.fail(rc, "%s", ratio_msg);
     // new_challenge = BLAKE2b(response) | decompressed elements
@@ -1501,6 +1533,32 @@ int ptau_power_pairs(int curve, int group, const uint8_t *in, int compressed_in,
     const ptau::ScalarSource src{ptau::SCALAR_PRF, nullptr, s[0], s[1], index_base};
     // (sum rho_i P_i, sum rho_i P_{i+1}), i in [0, n-1): the same coefficients on the vector and on its shift
     return run_msm_dev(c, ops, (const uint8_t *)c->d_in, compressed_in, n - 1, src, out_a, out_b, 0, err);
+}
+
+int ptau_check_same_ratio_batch(int curve, const uint8_t *checks, uint64_t n, int *results, uint32_t *gt_out, int device, char *errbuf,
+                                size_t err_len) {
+    Err err{errbuf, err_len};
+    const ptau::PairingOps *po = get_pairing_ops(curve);
+    if (!po) return err.fail(PTAU_E_ARG, "unknown curve id %d", curve);
+    if (n && (!checks || !results)) return err.fail(PTAU_E_ARG, "null pointer argument");
+    if (!n) return PTAU_OK;
+    if (n > 4096) return err.fail(PTAU_E_ARG, "at most 4096 checks per call");
+    DeviceCtx *c;
+    int rc = ensure_ctx(device, c, err);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(hipSetDevice(device));
+    const size_t in_bytes = n * po->check_bytes, gt_bytes = gt_out ? n * (size_t)po->K * po->n32 * 4 : 0;
+    const size_t off_res = (in_bytes + 255) & ~(size_t)255, off_gt = off_res + ((n * sizeof(int) + 255) & ~(size_t)255);
+    if ((rc = grow(c->d_pair, c->pair_cap, off_gt + gt_bytes + 256, err))) return rc;
+    uint8_t *d = (uint8_t *)c->d_pair;
+    HIP_TRY(hipMemcpyAsync(d, checks, in_bytes, hipMemcpyHostToDevice, c->side_stream));
+    po->launch(c->side_stream, d, (int *)(d + off_res), gt_out ? (uint32_t *)(d + off_gt) : nullptr, (int)n);
+    HIP_TRY(hipMemcpyAsync(results, d + off_res, n * sizeof(int), hipMemcpyDeviceToHost, c->side_stream));
+    if (gt_out) HIP_TRY(hipMemcpyAsync(gt_out, d + off_gt, gt_bytes, hipMemcpyDeviceToHost, c->side_stream));
+    HIP_TRY(hipStreamSynchronize(c->side_stream));
+    HIP_TRY(hipGetLastError());
+    return PTAU_OK;
 }
 
 int ptau_check_same_ratio(int curve, const uint8_t *g1_a, const uint8_t *g1_b, const uint8_t *g2_c, const uint8_t *g2_d,
@@ -1685,23 +1743,20 @@ int ptau_transform_ratios(const ptau_params *full, const uint8_t *combined, size
                                    errbuf, err_len)))
             return rc;
     }
-    // G1 vectors against (tauG2[0], tauG2[1]); tauG2 against (tauG1[0], tauG1[1]); betaG2 against betaG1[0]
+    // G1 vectors against (tauG2[0], tauG2[1]); tauG2 against (tauG1[0], tauG1[1]); betaG2 against betaG1[0]:
+    // five same-ratio checks, one launch of the pairing kernel
+    std::vector<RatioJob> jobs;
     for (int k : {0, 2, 3}) {
         const uint8_t *pa = pairs.data() + (size_t)k * 2 * g2->uncomp;
-        rc = ptau_check_same_ratio(full->curve, pa, pa + g2->uncomp, v_tau_g2, v_tau_g2 + g2->uncomp, errbuf, err_len);
-        if (rc == PTAU_E_INVALID_RATIO) return err.fail(rc, "power ratio check failed for %s", vec[k].name);
-        if (rc) return rc;
+        jobs.push_back({pa, pa + g2->uncomp, v_tau_g2, v_tau_g2 + g2->uncomp, std::string("power ratio check failed for ") + vec[k].name});
     }
     {
         const uint8_t *pa = pairs.data() + (size_t)1 * 2 * g2->uncomp;
-        rc = ptau_check_same_ratio(full->curve, v_tau_g1, v_tau_g1 + g1->uncomp, pa, pa + g2->uncomp, errbuf, err_len);
-        if (rc == PTAU_E_INVALID_RATIO) return err.fail(rc, "power ratio check failed for tau_g2");
-        if (rc) return rc;
+        jobs.push_back({v_tau_g1, v_tau_g1 + g1->uncomp, pa, pa + g2->uncomp, "power ratio check failed for tau_g2"});
     }
     // e(G1, betaG2) == e(betaG1[0], G2): (tauG1[0], betaG1[0]) ~ (tauG2[0], betaG2)
-    rc = ptau_check_same_ratio(full->curve, v_tau_g1, v_beta, v_tau_g2, v_beta_g2, errbuf, err_len);
-    if (rc == PTAU_E_INVALID_RATIO) return err.fail(rc, "beta_g2 is not consistent with beta_g1[0]");
-    return rc;
+    jobs.push_back({v_tau_g1, v_beta, v_tau_g2, v_beta_g2, "beta_g2 is not consistent with beta_g1[0]"});
+    return run_ratio_jobs(full->curve, jobs, err, device);
 }
 
 int ptau_verify_pok(const ptau_params *p, const uint8_t *challenge, size_t challenge_len, const uint8_t *response,

@@ -152,7 +152,7 @@ struct FpL {
     }
 
     // a + b mod p
-    PTAU_HD static FpL add(const FpL &a, const FpL &b) {
+    PTAU_HD static FpL add_inl(const FpL &a, const FpL &b) {
         const bool hi = hi_lane();
         uint32_t d[H], s[H];
         int32_t cy = 0;
@@ -180,7 +180,7 @@ struct FpL {
         for (int j = 0; j < H; j++) r.l[j] = borrow ? s[j] : d[j];
         return r;
     }
-    PTAU_HD static FpL sub(const FpL &a, const FpL &b) {
+    PTAU_HD static FpL sub_inl(const FpL &a, const FpL &b) {
         const bool hi = hi_lane();
         uint32_t d[H];
         int32_t cy = 0;
@@ -230,6 +230,58 @@ struct FpL {
         return r;
     }
     PTAU_HD static FpL dbl(const FpL &a) { return add(a, a); }
+#ifndef PTAU_FPL_ADD_CALLS
+#define PTAU_FPL_ADD_CALLS 0   // 1: sums and differences as register-ABI calls instead of ~230 inlined instructions each — measured 2-4 % slower (BW6-761, MNT G1)
+#endif
+    typedef uint32_t VecA __attribute__((ext_vector_type(H)));
+    __device__ __noinline__ static VecA add_vec(VecA a, VecA b) {
+        FpL x, y;
+#pragma unroll
+        for (int j = 0; j < H; j++) { x.l[j] = a[j]; y.l[j] = b[j]; }
+        const FpL r = add_inl(x, y);
+        VecA o;
+#pragma unroll
+        for (int j = 0; j < H; j++) o[j] = r.l[j];
+        return o;
+    }
+    __device__ __noinline__ static VecA sub_vec(VecA a, VecA b) {
+        FpL x, y;
+#pragma unroll
+        for (int j = 0; j < H; j++) { x.l[j] = a[j]; y.l[j] = b[j]; }
+        const FpL r = sub_inl(x, y);
+        VecA o;
+#pragma unroll
+        for (int j = 0; j < H; j++) o[j] = r.l[j];
+        return o;
+    }
+    PTAU_HD static FpL add(const FpL &a, const FpL &b) {
+#if defined(__HIP_DEVICE_COMPILE__) && PTAU_FPL_ADD_CALLS
+        VecA x, y;
+#pragma unroll
+        for (int j = 0; j < H; j++) { x[j] = a.l[j]; y[j] = b.l[j]; }
+        const VecA o = add_vec(x, y);
+        FpL r;
+#pragma unroll
+        for (int j = 0; j < H; j++) r.l[j] = o[j];
+        return r;
+#else
+        return add_inl(a, b);
+#endif
+    }
+    PTAU_HD static FpL sub(const FpL &a, const FpL &b) {
+#if defined(__HIP_DEVICE_COMPILE__) && PTAU_FPL_ADD_CALLS
+        VecA x, y;
+#pragma unroll
+        for (int j = 0; j < H; j++) { x[j] = a.l[j]; y[j] = b.l[j]; }
+        const VecA o = sub_vec(x, y);
+        FpL r;
+#pragma unroll
+        for (int j = 0; j < H; j++) r.l[j] = o[j];
+        return r;
+#else
+        return sub_inl(a, b);
+#endif
+    }
 
     // ---- Montgomery product, accumulator row distributed over the pair (see the header comment) ----
     typedef uint32_t VecH __attribute__((ext_vector_type(H)));

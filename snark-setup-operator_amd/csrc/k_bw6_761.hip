@@ -1,5 +1,6 @@
 // Kernel instantiations for one curve (G1 and G2) — see kernels_impl.hpp.
 #include "kernels_impl.hpp"
+#include "pairing_dev.hpp"
 
 namespace ptau {
 // BW6-761's base field is held as 28 limbs of 29 bits in every kernel (gen_constants.py RADIX29_LIMBS)
@@ -13,5 +14,10 @@ const GroupOps *ops_bw6_761(int group) {
     static const GroupOps o1 = Launch<G1T, G1S>::ops();
     static const GroupOps o2 = Launch<G2T, G2S>::ops();
     return group == 1 ? &o1 : (group == 2 ? &o2 : nullptr);
+}
+
+const PairingOps *pairing_ops_bw6_761() {
+    static const PairingOps o = PairingLaunch<TatePairingDev<Bw6FqR29, Bw6Fr, Bw6G1Cfg, Bw6G2Cfg, Bw6PairingCfg>>::ops();
+    return &o;
 }
 }  // namespace ptau

@@ -1,5 +1,6 @@
 // Kernel instantiations for one curve (G1 and G2) — see kernels_impl.hpp.
 #include "kernels_impl.hpp"
+#include "pairing_dev.hpp"
 
 namespace ptau {
 using G1T = GroupTypes<Mnt6FqR29, Mnt6Fr, Mnt6G1Cfg>;
@@ -12,5 +13,10 @@ const GroupOps *ops_mnt6_753(int group) {
     static const GroupOps o1 = Launch<G1T, G1S>::ops();
     static const GroupOps o2 = Launch<G2T, G2S>::ops();
     return group == 1 ? &o1 : (group == 2 ? &o2 : nullptr);
+}
+
+const PairingOps *pairing_ops_mnt6_753() {
+    static const PairingOps o = PairingLaunch<TatePairingDev<Mnt6FqR29, Mnt6Fr, Mnt6G1Cfg, Mnt6G2Cfg, Mnt6PairingCfg>>::ops();
+    return &o;
 }
 }  // namespace ptau

@@ -355,6 +355,28 @@ def check_same_ratio(curve, g1_pair, g2_pair) -> bool:
     return True
 
 
+def check_same_ratio_batch(curve, checks, want_gt=False, device=0):
+    """n same-ratio checks in one launch of the GPU pairing kernel.  checks: list of ((g1_a, g1_b), (g2_c, g2_d)) uncompressed
+    byte strings.  Returns the list of results (1 / 0 / -1) and, with want_gt, per check the GT value as k lists of ints."""
+    L = _lib.load_library()
+    c = curve_from_str(curve) if isinstance(curve, str) else int(curve)
+    n = len(checks)
+    blob = b"".join(g1[0] + g1[1] + g2[0] + g2[1] for g1, g2 in checks)
+    res = (ctypes.c_int * max(1, n))()
+    k = {0: 12, 1: 6, 2: 4, 3: 6}[c]
+    n32 = (L.ptau_point_size(c, 1, 1) * 8 + 31) // 32
+    gt = (ctypes.c_uint32 * (n * k * n32))() if want_gt else None
+    eb = _lib.errbuf()
+    _lib.check(L.ptau_check_same_ratio_batch(c, blob, n, res, gt, device, eb, len(eb)), eb)
+    out = list(res)[:n]
+    if not want_gt:
+        return out
+    vals = []
+    for t in range(n):
+        vals.append([sum(int(gt[(t * k + j) * n32 + w]) << (32 * w) for w in range(n32)) for j in range(k)])
+    return out, vals
+
+
 def new_challenge(challenge_filename, challenge_hash_filename, parameters: Phase1Parameters):
     """phase1_cli::new_challenge (new_setup.rs:105-109)."""
     L = _lib.load_library()
