@@ -231,23 +231,28 @@ MAC_PEAK = 32.7e12        # measured v_mad_u64_u32 issue peak, lane-MACs/s chip-
 
 def macs_per_update(curve, group, endo):
     """32x32->64 multiply-accumulates of one prime-field G1-type update, from the formulas the kernel runs:
-    product 2 N^2, square N^2 + N (N + 1) / 2; doubling 2M + 5S (a = 0) or 3M + 6S (+ a small a * Z^4 chain); full addition
-    11M + 5S; table of 8 multiples by 7 mixed additions (7M + 4S); signed 4-bit windows (15/16 of the digits are non-zero).
+    product 2 N^2, square N^2 + N (N + 1) / 2 (lane-split fields square with the product: 2 N^2); doubling 2M + 5S (a = 0) or
+    3M + 6S (+ a small a * Z^4 chain); table of 8 multiples by 7 mixed additions (7M + 4S); signed 4-bit windows (15/16 of
+    the digits are non-zero); window additions: mixed (7M + 4S) on the common-Z table of the j = 0 curves (+ 51 products to
+    rescale the table), full (11M + 5S) on the MNT curves.
     None for the extension-field groups (their base-product count depends on the lane mapping; not modelled)."""
     if group != 1 and curve != "bw6":
         return None
     n = FIELD_LIMBS[curve]
-    m, sq = 2 * n * n, n * n + n * (n + 1) // 2
+    m = 2 * n * n
+    sq = m if curve != "bls12_377" else n * n + n * (n + 1) // 2
     a_zero = curve in ("bls12_377", "bw6")
     dbl = 2 * m + 5 * sq if a_zero else 3 * m + 6 * sq
-    add, madd = 11 * m + 5 * sq, 7 * m + 4 * sq
+    madd = 7 * m + 4 * sq
+    add = madd if a_zero else 11 * m + 5 * sq
+    rescale = 51 * m if a_zero else 0
     bits = SCALAR_BITS[curve]
     if endo and a_zero:
         half = 128 if curve == "bls12_377" else 192
         windows = half // 4
-        return (4 * windows - 4) * dbl + 2 * windows * 15 // 16 * add + windows * 15 // 16 * m + 7 * madd
+        return (4 * windows - 4) * dbl + 2 * windows * 15 // 16 * add + windows * 15 // 16 * m + 7 * madd + rescale
     windows = (bits + 3 + 3) // 4
-    return (4 * windows - 4) * dbl + windows * 15 // 16 * add + 7 * madd
+    return (4 * windows - 4) * dbl + windows * 15 // 16 * add + 7 * madd + rescale
 
 
 def pmc_for(tag):

@@ -76,6 +76,17 @@ struct GroupTypes {
     // otherwise) is what gets BW6-761 and MNT G1 to two waves.
     static constexpr bool SMALL = F::DEG == 1 && F::POINT_OPS_INLINE;   // a point operation inlines at <= 256 registers
     static constexpr int K1_MIN_WAVES = (LPP == 1 && SMALL) ? PTAU_K1_G1_MIN_WAVES : 0;   // 0: same as MIN_WAVES
+    // K1's per-point window table with a COMMON Z (no inversion): the eight multiples are rescaled to one denominator Zc =
+    // prod Z_e (~50 products), which makes them AFFINE points of the isomorphic curve y^2 = x^3 + b Zc^6.  On a j = 0 curve
+    // neither the doubling nor the mixed addition involves b, and (x, y) -> (beta x, y) is the same endomorphism there, so
+    // the whole window loop runs on that curve with mixed additions (7M + 4S instead of 11M + 5S, two coordinates per
+    // table entry instead of three) and the result (X, Y, Z) maps back as (X, Y, Z Zc).  Exact for every curve point.
+    // (A per-point inversion for a truly affine table was measured first: the binary inversion diverges across lanes and
+    // cost ~400 products per point — 5 % slower than the Jacobian table.)
+#ifndef PTAU_AFFINE_TABLE
+#define PTAU_AFFINE_TABLE 1
+#endif
+    static constexpr bool AFFINE_TABLE = PTAU_AFFINE_TABLE && Cfg::A_IS_ZERO && F::DEG == 1 && F::POINT_OPS_INLINE;
     static constexpr int MIN_WAVES = LANE_MODE == LANES_LIMB_SPLIT ? PTAU_SPLIT_MIN_WAVES : LPP == 2 ? PTAU_LANE_MIN_WAVES : SMALL ? PTAU_G1_MIN_WAVES : (PTAU_MIN_WAVES_WIDE > 0 ? PTAU_MIN_WAVES_WIDE : 1);
 };
 
@@ -441,10 +452,66 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
     const uint64_t slot = i * G::LPP + (G::LPP == 2 ? lane_parity() : 0u), nslots = n * G::LPP;
     J cur = J::from_affine(p);
     wtab[slot] = cur;
-    for (int e = 1; e < WINDOW_ENTRIES; e++) {
-        cur = J::add_mixed(cur, p);
-        wtab[(uint64_t)e * nslots + slot] = cur;
+    F zc = F::one();   // the table's common denominator (AFFINE_TABLE)
+    if constexpr (G::AFFINE_TABLE) {
+        // Jacobian multiples first, the running product of their Z's on the side; then, last to first, entry e is scaled by
+        // c_e = Zc / Z_e = (product of the Z's before it) * (product of those after it): (X c^2, Y c^3) written to its X and
+        // Y slots.  (0, 0), which is on no curve with b != 0, marks the point at infinity — a multiple of a small-order
+        // point outside the subgroup can be O; such entries are left out of the product.
+        F pre[WINDOW_ENTRIES - 1];
+#pragma nounroll
+        for (int e = 1; e < WINDOW_ENTRIES; e++) {
+            cur = J::add_mixed(cur, p);
+            wtab[(uint64_t)e * nslots + slot] = cur;
+            pre[e - 1] = zc;
+            if (!cur.Z.is_zero()) zc = F::mul(zc, cur.Z);
+        }
+        F suf = F::one();
+#pragma nounroll
+        for (int e = WINDOW_ENTRIES - 1; e >= 1; e--) {
+            J q = wtab[(uint64_t)e * nslots + slot];
+            if (q.Z.is_zero()) {
+                q.X = F::zero();
+                q.Y = F::zero();
+            } else {
+                const F c = F::mul(pre[e - 1], suf);
+                suf = F::mul(suf, q.Z);
+                const F c2 = F::sqr(c);
+                q.X = F::mul(q.X, c2);
+                q.Y = F::mul(q.Y, F::mul(c2, c));
+            }
+            wtab[(uint64_t)e * nslots + slot].X = q.X;
+            wtab[(uint64_t)e * nslots + slot].Y = q.Y;
+        }
+        {   // entry 0 = P itself (Z = 1): c = Zc
+            const F c2 = F::sqr(zc);
+            wtab[slot].X = F::mul(p.x, c2);
+            wtab[slot].Y = F::mul(p.y, F::mul(c2, zc));
+        }
+    } else {
+        for (int e = 1; e < WINDOW_ENTRIES; e++) {
+            cur = J::add_mixed(cur, p);
+            wtab[(uint64_t)e * nslots + slot] = cur;
+        }
     }
+    // acc += (+-) table entry `mag` (with the GLV endomorphism applied when `endo`): a mixed addition on an affine table
+    auto add_entry = [&](J &acc, int mag, bool negate, bool endo, const F &beta) {
+        if constexpr (G::AFFINE_TABLE) {
+            const J *t = &wtab[(uint64_t)(mag - 1) * nslots + slot];
+            A q;
+            q.x = t->X;
+            q.y = t->Y;
+            q.inf = q.x.is_zero() && q.y.is_zero();
+            if (endo) q.x = F::mul(q.x, beta);
+            if (negate) q.y = F::neg(q.y);
+            acc = J::add_mixed(acc, q);
+        } else {
+            J ent = wtab[(uint64_t)(mag - 1) * nslots + slot];
+            if (endo) ent.X = F::mul(ent.X, beta);
+            if (negate) ent.Y = F::neg(ent.Y);
+            acc = J::add(acc, ent);
+        }
+    };
     uint32_t k[NL];
     thread_scalar<Fr>(src, i, k);
     using Cfg = typename J::CfgT;
@@ -478,13 +545,11 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
                     int dgt = (int)((limb >> ((w & 7) * 4)) & 15u) - 8;
                     if (dgt != 0) {
                         int mag = dgt < 0 ? -dgt : dgt;
-                        J ent = wtab[(uint64_t)(mag - 1) * nslots + slot];
-                        if (h) ent.X = F::mul(ent.X, beta);
-                        if ((dgt < 0) != (h ? ng[1] : ng[0])) ent.Y = F::neg(ent.Y);
-                        acc = J::add(acc, ent);
+                        add_entry(acc, mag, (dgt < 0) != (h ? ng[1] : ng[0]), h != 0, beta);
                     }
                 }
             }
+            if constexpr (G::AFFINE_TABLE) acc.Z = F::mul(acc.Z, zc);   // back from the isomorphic curve
             store_jac<G>(scratch, i, acc);
             return 0;
         }
@@ -556,11 +621,10 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
         int dgt = (int)((limb >> ((w & 7) * 4)) & 15u) - 8;
         if (dgt != 0) {
             int mag = dgt < 0 ? -dgt : dgt;
-            J ent = wtab[(uint64_t)(mag - 1) * nslots + slot];
-            if (dgt < 0) ent.Y = F::neg(ent.Y);
-            acc = J::add(acc, ent);
+            add_entry(acc, mag, dgt < 0, false, F::zero());
         }
     }
+    if constexpr (G::AFFINE_TABLE) acc.Z = F::mul(acc.Z, zc);   // back from the isomorphic curve
     store_jac<G>(scratch, i, acc);
     return 0;
 }
