@@ -86,7 +86,7 @@ struct GroupTypes {
 #ifndef PTAU_AFFINE_TABLE
 #define PTAU_AFFINE_TABLE 1
 #endif
-    static constexpr bool AFFINE_TABLE = PTAU_AFFINE_TABLE && Cfg::A_IS_ZERO && F::DEG == 1 && F::POINT_OPS_INLINE;
+    static constexpr bool AFFINE_TABLE = PTAU_AFFINE_TABLE && Cfg::A_IS_ZERO && F::DEG <= 2 && F::POINT_OPS_INLINE;
     static constexpr int MIN_WAVES = LANE_MODE == LANES_LIMB_SPLIT ? PTAU_SPLIT_MIN_WAVES : LPP == 2 ? PTAU_LANE_MIN_WAVES : SMALL ? PTAU_G1_MIN_WAVES : (PTAU_MIN_WAVES_WIDE > 0 ? PTAU_MIN_WAVES_WIDE : 1);
 };
 
@@ -466,7 +466,10 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
             pre[e - 1] = zc;
             if (!cur.Z.is_zero()) zc = F::mul(zc, cur.Z);
         }
+        // Fq2 (BLS12-377 G2): the common denominator is made REAL — Zc * conj(Zc), in Fq — so that psi, which conjugates Z,
+        // maps table entries to points with the same denominator (the GLS path applies psi^j to the entries on the fly)
         F suf = F::one();
+        if constexpr (F::DEG == 2) suf = F::conj(zc);
 #pragma nounroll
         for (int e = WINDOW_ENTRIES - 1; e >= 1; e--) {
             J q = wtab[(uint64_t)e * nslots + slot];
@@ -484,6 +487,7 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
             wtab[(uint64_t)e * nslots + slot].Y = q.Y;
         }
         {   // entry 0 = P itself (Z = 1): c = Zc
+            if constexpr (F::DEG == 2) zc = F::mul(zc, F::conj(zc));
             const F c2 = F::sqr(zc);
             wtab[slot].X = F::mul(p.x, c2);
             wtab[slot].Y = F::mul(p.y, F::mul(c2, zc));
@@ -584,7 +588,7 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
                     const int dgt = (int)nib - 8;
                     if (dgt != 0) {
                         const int mag = dgt < 0 ? -dgt : dgt;
-                        J ent = wtab[(uint64_t)(mag - 1) * nslots + slot];
+                        J ent = wtab[(uint64_t)(mag - 1) * nslots + slot];   // affine table: Z slot unused (real common Z)
                         if (h) {
                             B cx, cy;
 #pragma unroll
@@ -592,16 +596,25 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
                             if (h & 1) {   // odd powers of psi conjugate
                                 ent.X = F::conj(ent.X);
                                 ent.Y = F::conj(ent.Y);
-                                ent.Z = F::conj(ent.Z);
+                                if constexpr (!G::AFFINE_TABLE) ent.Z = F::conj(ent.Z);
                             }
                             ent.X = F::mul_base(ent.X, cx);
                             ent.Y = F::mul_base(ent.Y, cy);
                         }
                         if (dgt < 0) ent.Y = F::neg(ent.Y);
-                        acc = J::add(acc, ent);
+                        if constexpr (G::AFFINE_TABLE) {
+                            A q;
+                            q.x = ent.X;
+                            q.y = ent.Y;
+                            q.inf = q.x.is_zero() && q.y.is_zero();
+                            acc = J::add_mixed(acc, q);
+                        } else {
+                            acc = J::add(acc, ent);
+                        }
                     }
                 }
             }
+            if constexpr (G::AFFINE_TABLE) acc.Z = F::mul(acc.Z, zc);   // back from the isomorphic curve
             store_jac<G>(scratch, i, acc);
             return 0;
         }
