@@ -751,7 +751,11 @@ struct MappedFile {
     void *p = MAP_FAILED;
     size_t len = 0;
     int fd = -1;
+    std::future<void> populate;   // background page population / registration of an output mapping
+    bool registered = false;
     ~MappedFile() {
+        if (populate.valid()) populate.wait();
+        if (registered) (void)hipHostUnregister(p);
         if (p != MAP_FAILED) munmap(p, len);
         if (fd >= 0) close(fd);
     }
@@ -774,6 +778,24 @@ struct MappedFile {
         len = size;
         p = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
         if (p == MAP_FAILED) return err.fail(PTAU_E_IO, "cannot mmap %s: %s", path, strerror(errno));
+        // Staging of the output file: the 250-600 MB of results arrive by D2H copies into this mapping;
+        // into freshly created, never-touched pages every 4 KB of a copy takes a page fault in the driver's copy path
+        // (80 ms of D2H for a 503 MB new challenge).  The pages are faulted in here, on a host thread, while the GPU is still
+        // computing — MADV_POPULATE_WRITE does not modify their content, so it may run beside the copies — and the
+        // populated range is then page-locked and registered with the HIP runtime (DMA straight into the file's pages,
+        // no bounce buffer) unless PTAU_HOST_REGISTER=0.
+        populate = std::async(std::launch::async, [this] {
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23
+#endif
+            if (madvise(p, len, MADV_POPULATE_WRITE) != 0) return;
+            static const bool want_register = [] {
+                const char *e = getenv("PTAU_HOST_REGISTER");
+                return !(e && e[0] == '0');
+            }();
+            if (want_register && hipHostRegister(p, len, hipHostRegisterPortable) == hipSuccess) registered = true;
+            else (void)hipGetLastError();
+        });
         return PTAU_OK;
     }
 };

@@ -183,17 +183,34 @@ struct ScalarSource {
     uint64_t index_base;      // PRF: global index of element 0 (slices of one vector agree across GPUs)
 };
 
-PTAU_HD uint64_t splitmix64(uint64_t z) {
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-// word j of the random coefficient rho_idx of merge_pairs / power_pairs (setup-utils draws Fr::rand from
-// thread_rng; here a counter-based generator keyed by a per-verification 128-bit secret, so that any slice
-// of a vector, on any GPU, sees the same rho for the same global index).  rho = words 0..3, top bit cleared (PRF_BITS = 127).
-PTAU_HD uint32_t prf_word(uint64_t seed0, uint64_t seed1, uint64_t idx, int nl, int j) {
-    uint64_t z = splitmix64(seed0 + (idx * (uint64_t)nl + (uint64_t)j + 1) * 0x9E3779B97F4A7C15ull) ^ seed1;
-    return (uint32_t)(splitmix64(z) >> 32);
+// The random coefficient rho_idx of merge_pairs / power_pairs.  setup-utils draws Fr::rand from thread_rng — rand 0.8's
+// ChaCha12 generator; here the SAME cipher as a counter-mode PRF, so that any slice of a vector, on any GPU, sees the same
+// rho for the same global index: one ChaCha12 block per element, key = the per-verification 128-bit secret (from the OS)
+// followed by a fixed domain tag, block counter = the element's global index; rho = words 0..3 of the block with the top bit
+// cleared (PRF_BITS = 127).  ~600 plain ALU operations per element, against the ~1400 of converting the point.
+PTAU_HD uint32_t prf_rotl(uint32_t v, int n) { return (v << n) | (v >> (32 - n)); }
+PTAU_HD void prf_rho(uint64_t seed0, uint64_t seed1, uint64_t idx, uint32_t (&out)[4]) {
+    const uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u,
+                            (uint32_t)seed0, (uint32_t)(seed0 >> 32), (uint32_t)seed1, (uint32_t)(seed1 >> 32),
+                            0x75617470u /* "ptau" */, 0x6f68722du /* "-rho" */, 0x72657020u, 0x78646e69u,
+                            (uint32_t)idx, (uint32_t)(idx >> 32), 0u, 0u};
+    uint32_t x[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) x[i] = s[i];
+#define PTAU_QR(a, b, c, d)                                   \
+    x[a] += x[b]; x[d] = prf_rotl(x[d] ^ x[a], 16);          \
+    x[c] += x[d]; x[b] = prf_rotl(x[b] ^ x[c], 12);          \
+    x[a] += x[b]; x[d] = prf_rotl(x[d] ^ x[a], 8);           \
+    x[c] += x[d]; x[b] = prf_rotl(x[b] ^ x[c], 7);
+#pragma unroll
+    for (int r = 0; r < 6; r++) {   // ChaCha12: six double rounds
+        PTAU_QR(0, 4, 8, 12) PTAU_QR(1, 5, 9, 13) PTAU_QR(2, 6, 10, 14) PTAU_QR(3, 7, 11, 15)
+        PTAU_QR(0, 5, 10, 15) PTAU_QR(1, 6, 11, 12) PTAU_QR(2, 7, 8, 13) PTAU_QR(3, 4, 9, 14)
+    }
+#undef PTAU_QR
+#pragma unroll
+    for (int i = 0; i < 4; i++) out[i] = x[i] + s[i];
+    out[3] &= 0x7fffffffu;
 }
 
 // Number of random bits in a power_pairs coefficient.  setup-utils draws full-width Fr::rand; the check
@@ -213,9 +230,10 @@ PTAU_HD void thread_scalar(const ScalarSource &src, uint64_t i, uint32_t (&k)[Fr
         for (int j = 0; j < NL; j++) k[j] = src.ptr[i * NL + j];
     } else if (src.mode == SCALAR_PRF) {     // random linear combination coefficients
         static_assert(NL * 32 >= PRF_BITS && Fr::Params::BITS > PRF_BITS, "scalar field too small for the PRF width");
+        uint32_t rho[4];
+        prf_rho(src.seed0, src.seed1, src.index_base + i, rho);
 #pragma unroll
-        for (int j = 0; j < NL; j++) k[j] = j < 4 ? prf_word(src.seed0, src.seed1, src.index_base + i, NL, j) : 0u;
-        k[3] &= 0x7fffffffu;
+        for (int j = 0; j < NL; j++) k[j] = j < 4 ? rho[j] : 0u;
     } else {
         Fr ek = scalar_for_index<Fr>(src.ptr, i);
         ek.to_canonical(k);

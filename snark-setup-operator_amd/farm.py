@@ -11,9 +11,17 @@ import os
 from typing import Callable, Dict, List, Sequence, Tuple
 
 
-def chunk_weight(g1_chunk_size: int, other_chunk_size: int, g2_cost: float = 3.0) -> float:
-    """Relative cost of one chunk: tauG1 + (tauG2 + alphaG1 + betaG1) elements; a G2 update costs about
-    g2_cost G1 updates (Fq2 arithmetic)."""
+# Cost of one G2 update in G1 updates, measured on MI355X this round (profiles/r02_*: kernel time per element of the two
+# groups' tau-update, exact path; the endomorphism path of BLS12-377 gives 4.3): Fq2 arithmetic on BLS12-377 and MNT4-753,
+# Fq3 on MNT6-753, the same base field on BW6-761.
+G2_COST = {"bls12_377": 5.2, "bw6": 1.0, "mnt4_753": 4.4, "mnt6_753": 9.7}
+
+
+def chunk_weight(g1_chunk_size: int, other_chunk_size: int, curve: str = "bls12_377", g2_cost: float = None) -> float:
+    """Relative cost of one chunk: tauG1 + (tauG2 + alphaG1 + betaG1) elements; a G2 update costs g2_cost G1 updates
+    (per-curve measured ratio unless given)."""
+    if g2_cost is None:
+        g2_cost = G2_COST[curve]
     return g1_chunk_size + other_chunk_size * (2.0 + g2_cost)
 
 
@@ -45,7 +53,8 @@ def run_farm(n_chunks: int, weights: Sequence[float], process_chunk: Callable[[i
     for part in gathered:
         for i, h in part:
             result[i] = h
-    assert sorted(result) == list(range(n_chunks)), "a chunk was dropped or duplicated by the farm"
+    if sorted(result) != list(range(n_chunks)):      # not an assert: must hold under python -O as well
+        raise RuntimeError("a chunk was dropped or duplicated by the farm: got %r of %d" % (sorted(result), n_chunks))
     return result
 
 
@@ -78,20 +87,23 @@ def accumulator_vectors(point_sizes: Dict[int, int], powers_g1_length: int, powe
     return out, o
 
 
-def sharded_transform_ratios(combined: bytes, point_sizes: Dict[int, int], powers_g1_length: int, powers_length: int,
+def sharded_transform_ratios(combined, point_sizes: Dict[int, int], powers_g1_length: int, powers_length: int,
                              power_pairs: Callable, sum_points: Callable, check_same_ratio: Callable, dist=None,
-                             seed: bytes = None) -> bool:
+                             seed: bytes = None, device: int = 0) -> bool:
     """transform_ratios with the four vector reductions split over the ranks of `dist`.
 
     power_pairs(group, data, n, seed, index_base) -> (a, b)   reduces n consecutive points (n - 1 pairs) of one slice;
     sum_points(group, [points])                 -> point     adds serialized points;
     check_same_ratio((a, b), (c, d))            -> bool      the pairing test, G1 pair vs G2 pair.
     On GPUs these are phase1_cli.power_pairs / dense_multiexp with unit scalars / check_same_ratio; the CPU tests
-    inject oracle stand-ins.  Every rank returns the same verdict."""
+    inject oracle stand-ins.  Every rank returns the same verdict.
+    `combined` is any buffer (bytes, or a memory-mapped file): a rank copies only ITS slice of each vector out of it.
+    `device`: this rank's GPU ordinal (the tensors of the RCCL collectives live there)."""
     import torch
     world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
-    dev = "cuda" if (dist is not None and dist.get_backend() == "nccl") else "cpu"
+    dev = torch.device("cuda", device) if (dist is not None and dist.get_backend() == "nccl") else torch.device("cpu")
+    combined = memoryview(combined)
     if seed is None:
         seed = os.urandom(16)
     if dist is not None:   # one coefficient stream for the whole vector: rank 0's seed
@@ -104,7 +116,7 @@ def sharded_transform_ratios(combined: bytes, point_sizes: Dict[int, int], power
         usz = point_sizes[grp]
         lo, hi = slice_bounds(cnt - 1, world, rank)
         if hi > lo:      # points lo .. hi inclusive
-            a, b = power_pairs(grp, combined[off + lo * usz: off + (hi + 1) * usz], hi - lo + 1, seed, lo)
+            a, b = power_pairs(grp, bytes(combined[off + lo * usz: off + (hi + 1) * usz]), hi - lo + 1, seed, lo)
             part = a + b + b"\x01"
         else:
             part = bytes(2 * usz) + b"\x00"      # no pairs on this rank
@@ -119,13 +131,14 @@ def sharded_transform_ratios(combined: bytes, point_sizes: Dict[int, int], power
         reduced[name] = (sum_points(grp, [p[:usz] for p in parts]), sum_points(grp, [p[usz:2 * usz] for p in parts]))
     u1, u2 = point_sizes[1], point_sizes[2]
     v = {name: off for name, _, off, _ in vectors}
-    tau_g1_01 = (combined[v["tau_g1"]: v["tau_g1"] + u1], combined[v["tau_g1"] + u1: v["tau_g1"] + 2 * u1])
-    tau_g2_01 = (combined[v["tau_g2"]: v["tau_g2"] + u2], combined[v["tau_g2"] + u2: v["tau_g2"] + 2 * u2])
+    cut = lambda a, b: bytes(combined[a:b])
+    tau_g1_01 = (cut(v["tau_g1"], v["tau_g1"] + u1), cut(v["tau_g1"] + u1, v["tau_g1"] + 2 * u1))
+    tau_g2_01 = (cut(v["tau_g2"], v["tau_g2"] + u2), cut(v["tau_g2"] + u2, v["tau_g2"] + 2 * u2))
     ok = True
     for name in ("tau_g1", "alpha_g1", "beta_g1"):
         ok = ok and check_same_ratio(reduced[name], tau_g2_01)
     ok = ok and check_same_ratio(tau_g1_01, reduced["tau_g2"])
-    beta_g1_0 = combined[v["beta_g1"]: v["beta_g1"] + u1]
-    beta_g2 = combined[beta_g2_off: beta_g2_off + u2]
+    beta_g1_0 = cut(v["beta_g1"], v["beta_g1"] + u1)
+    beta_g2 = cut(beta_g2_off, beta_g2_off + u2)
     ok = ok and check_same_ratio((tau_g1_01[0], beta_g1_0), (tau_g2_01[0], beta_g2))
     return bool(ok)

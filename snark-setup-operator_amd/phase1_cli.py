@@ -311,24 +311,30 @@ def dense_multiexp(curve, group, data: bytes, scalars, compressed_in=False, comp
     return out.raw
 
 
-MASK64 = (1 << 64) - 1
+def _chacha12_block(key_words, counter):
+    M = 0xFFFFFFFF
+    s = [0x61707865, 0x3320646E, 0x79622D32, 0x6B206574] + list(key_words) + [counter & M, (counter >> 32) & M, 0, 0]
+    x = list(s)
+    rot = lambda v, n: ((v << n) | (v >> (32 - n))) & M
+
+    def qr(a, b, c, d):
+        x[a] = (x[a] + x[b]) & M; x[d] = rot(x[d] ^ x[a], 16)
+        x[c] = (x[c] + x[d]) & M; x[b] = rot(x[b] ^ x[c], 12)
+        x[a] = (x[a] + x[b]) & M; x[d] = rot(x[d] ^ x[a], 8)
+        x[c] = (x[c] + x[d]) & M; x[b] = rot(x[b] ^ x[c], 7)
+    for _ in range(6):
+        qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15)
+        qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14)
+    return [(a + b) & M for a, b in zip(x, s)]
 
 
-def _splitmix64(z):
-    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & MASK64
-    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & MASK64
-    return z ^ (z >> 31)
-
-
-def power_pairs_coefficient(seed: bytes, idx: int, fr_bits: int) -> int:
-    """The coefficient rho_idx that ptau_power_pairs uses (documented PRF, kernels_impl.hpp::prf_word):
-    PRF_BITS = 127 random bits — words 0..3 of the per-index stream, top bit cleared."""
-    s0, s1 = int.from_bytes(seed[:8], "little"), int.from_bytes(seed[8:16], "little")
-    nl = (fr_bits + 31) // 32
-    v = 0
-    for j in range(4):
-        z = _splitmix64((s0 + (idx * nl + j + 1) * 0x9E3779B97F4A7C15) & MASK64) ^ s1
-        v |= (_splitmix64(z) >> 32) << (32 * j)
+def power_pairs_coefficient(seed: bytes, idx: int, fr_bits: int = 0) -> int:
+    """The coefficient rho_idx that ptau_power_pairs uses (documented PRF, kernels_impl.hpp::prf_rho): ChaCha12 in counter
+    mode — key = the 16-byte seed followed by the 16-byte tag "ptau-rho perindx", block counter = the element's global index —
+    words 0..3 of the block, top bit cleared (PRF_BITS = 127)."""
+    key = [int.from_bytes(seed[4 * i:4 * i + 4], "little") for i in range(4)] + [0x75617470, 0x6F68722D, 0x72657020, 0x78646E69]
+    w = _chacha12_block(key, idx)
+    v = w[0] | (w[1] << 32) | (w[2] << 64) | (w[3] << 96)
     return v & ((1 << 127) - 1)
 
 
@@ -434,7 +440,7 @@ def transform_ratios(combined: bytes, check_input_correctness, full_parameters: 
                                        int(check_input_correctness), device, eb, len(eb)), eb)
 
 
-def transform_ratios_sharded(combined: bytes, full_parameters: Phase1Parameters, dist=None, device=0, seed: bytes = None) -> None:
+def transform_ratios_sharded(combined, full_parameters: Phase1Parameters, dist=None, device=0, seed: bytes = None) -> None:
     """phase1_cli::transform_ratios with the vector reductions split over the ranks of an initialised
     torch.distributed group (one process per GPU; farm.sharded_transform_ratios): each rank runs ptau_power_pairs on
     its slice with the shared coefficient stream, ONE all_gather of the partial pairs per vector (RCCL over xGMI),
@@ -451,10 +457,10 @@ def transform_ratios_sharded(combined: bytes, full_parameters: Phase1Parameters,
     def sum_points(grp, pts):
         return dense_multiexp(curve, grp, b"".join(pts), [1] * len(pts), device=device)
 
-    def check(g1p, g2p):
-        return check_same_ratio(curve, g1p, g2p)
+    def check(g1p, g2p):     # the pairing kernel (K5 on the GPU)
+        return check_same_ratio_batch(curve, [(g1p, g2p)], device=device)[0] == 1
     ok = farm.sharded_transform_ratios(combined, sizes, full_parameters.powers_g1_length, full_parameters.powers_length,
-                                       pp, sum_points, check, dist=dist, seed=seed)
+                                       pp, sum_points, check, dist=dist, seed=seed, device=device)
     if not ok:
         raise _lib.PtauError(-6, "power ratio check failed (sharded transform_ratios)")
 
