@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "../../include/ptau.h"
+#include "blake2b_host.hpp"
 #include "kernels_impl.hpp"
 #include "pairing_dev.hpp"
 #include "pairing_host.hpp"
@@ -679,73 +680,7 @@ int check_params(const ptau_params *p, const Err &err) {
     return PTAU_OK;
 }
 
-// ---- BLAKE2b-512 (RFC 7693), host CPU -------------------------------------------------------
-struct Blake2b {
-    uint64_t h[8], t0 = 0, t1 = 0;
-    uint8_t buf[128];
-    size_t fill = 0;
-    static constexpr uint64_t IV[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL,
-                                       0xa54ff53a5f1d36f1ULL, 0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL,
-                                       0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
-    Blake2b() {
-        for (int i = 0; i < 8; i++) h[i] = IV[i];
-        h[0] ^= 0x01010040ULL;   // digest 64 bytes, no key, fanout = depth = 1
-    }
-    static uint64_t rotr(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
-    void compress(const uint8_t *blk, bool last) {
-        static const uint8_t S[10][16] = {
-            {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
-            {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
-            {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
-            {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
-            {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0}};
-        uint64_t m[16], v[16];
-        memcpy(m, blk, 128);
-        for (int i = 0; i < 8; i++) { v[i] = h[i]; v[i + 8] = IV[i]; }
-        v[12] ^= t0;
-        v[13] ^= t1;
-        if (last) v[14] = ~v[14];
-        auto G = [&](int a, int b, int c, int d, uint64_t x, uint64_t y) {
-            v[a] += v[b] + x; v[d] = rotr(v[d] ^ v[a], 32);
-            v[c] += v[d];     v[b] = rotr(v[b] ^ v[c], 24);
-            v[a] += v[b] + y; v[d] = rotr(v[d] ^ v[a], 16);
-            v[c] += v[d];     v[b] = rotr(v[b] ^ v[c], 63);
-        };
-        for (int r = 0; r < 12; r++) {
-            const uint8_t *s = S[r % 10];
-            G(0, 4, 8, 12, m[s[0]], m[s[1]]);   G(1, 5, 9, 13, m[s[2]], m[s[3]]);
-            G(2, 6, 10, 14, m[s[4]], m[s[5]]);  G(3, 7, 11, 15, m[s[6]], m[s[7]]);
-            G(0, 5, 10, 15, m[s[8]], m[s[9]]);  G(1, 6, 11, 12, m[s[10]], m[s[11]]);
-            G(2, 7, 8, 13, m[s[12]], m[s[13]]); G(3, 4, 9, 14, m[s[14]], m[s[15]]);
-        }
-        for (int i = 0; i < 8; i++) h[i] ^= v[i] ^ v[i + 8];
-    }
-    void add_count(uint64_t n) {
-        t0 += n;
-        if (t0 < n) t1++;
-    }
-    void update(const uint8_t *p, size_t n) {
-        while (n) {
-            if (fill == 128) {   // buffer full and more data follows: not the last block
-                add_count(128);
-                compress(buf, false);
-                fill = 0;
-            }
-            size_t k = std::min(n, (size_t)128 - fill);
-            memcpy(buf + fill, p, k);
-            fill += k;
-            p += k;
-            n -= k;
-        }
-    }
-    void finish(uint8_t out[64]) {
-        add_count(fill);
-        memset(buf + fill, 0, 128 - fill);
-        compress(buf, true);
-        memcpy(out, h, 64);
-    }
-};
-constexpr uint64_t Blake2b::IV[8];
+// BLAKE2b-512 (host CPU): blake2b_host.hpp / blake2b_host.cpp
 
 struct MappedFile {
     void *p = MAP_FAILED;
@@ -880,12 +815,6 @@ int ptau_params_sizes(const ptau_params *p, ptau_sizes *out) {
     out->accumulator_size = 64 + n1 * g1->uncomp + n2 * (g2->uncomp + 2ull * g1->uncomp) + g2->uncomp;
     out->contribution_size = 64 + n1 * g1->comp + n2 * (g2->comp + 2ull * g1->comp) + g2->comp + out->public_key_size;
     return PTAU_OK;
-}
-
-void ptau_blake2b512(const uint8_t *data, size_t len, uint8_t out[64]) {
-    Blake2b b;
-    b.update(data, len);
-    b.finish(out);
 }
 
 int ptau_last_timing(int device, ptau_timing *out) {

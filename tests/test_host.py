@@ -42,6 +42,20 @@ def test_host_blake2b(pkg, cref):
         assert pkg.calculate_hash(d) == hashlib.blake2b(d).digest() == cref.blake2b512(d)
 
 
+def test_blake2b_portable_and_avx2_agree(pkg):
+    """Both compression functions of the host BLAKE2b (portable, AVX2) against hashlib, on block-boundary lengths."""
+    L = pkg.load_library()
+    chosen = L.ptau_blake2b_implementation(-1)
+    data = bytes((i * 131 + 7) & 0xFF for i in range(70001))
+    try:
+        for impl in (0, 1):
+            L.ptau_blake2b_implementation(impl)
+            for n in (0, 1, 127, 128, 129, 255, 256, 257, 4096, 70001):
+                assert pkg.calculate_hash(data[:n]) == hashlib.blake2b(data[:n]).digest(), (impl, n)
+    finally:
+        L.ptau_blake2b_implementation(chosen)
+
+
 def test_mode_parsers_and_errors(pkg):
     assert pkg.batch_exp_mode_from_str("auto") == pkg.BatchExpMode.Auto
     assert pkg.subgroup_check_mode_from_str("batched") == pkg.SubgroupCheckMode.Batched
