@@ -44,6 +44,7 @@ def test_host_blake2b(pkg, cref):
 
 def test_blake2b_portable_and_avx2_agree(pkg):
     """Both compression functions of the host BLAKE2b (portable, AVX2) against hashlib, on block-boundary lengths."""
+    import hashlib
     L = pkg.load_library()
     chosen = L.ptau_blake2b_implementation(-1)
     data = bytes((i * 131 + 7) & 0xFF for i in range(70001))
