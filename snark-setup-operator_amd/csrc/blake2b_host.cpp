@@ -4,6 +4,7 @@
 #include <immintrin.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 
 #include "../../include/ptau.h"
@@ -90,10 +91,28 @@ __attribute__((target("avx2"))) void compress_avx2(uint64_t h[8], const uint8_t 
     _mm256_storeu_si256((__m256i *)&h[4], b);
 }
 
+// Which form is faster depends on the core (measured: AVX2 +14 % on a 2.1 GHz Xeon, -38 % on an EPYC 9575F, whose scalar
+// pipes beat the vpinsrq-built message vectors), so the first use times both on 512 KB and keeps the winner.
 int g_impl = -1;
 int pick() {
-    if (g_impl < 0) g_impl = __builtin_cpu_supports("avx2") ? 1 : 0;
-    return g_impl;
+    if (g_impl >= 0) return g_impl;
+    if (!__builtin_cpu_supports("avx2")) return g_impl = 0;
+    static uint8_t probe[128];
+    double best[2] = {1e30, 1e30};
+    for (int rep = 0; rep < 3; rep++)
+        for (int impl = 0; impl < 2; impl++) {
+            uint64_t hh[8];
+            memcpy(hh, IV, sizeof hh);
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < 4096; i++) {
+                if (impl) compress_avx2(hh, probe, 128ull * i, 0, false);
+                else compress_portable(hh, probe, 128ull * i, 0, false);
+            }
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            probe[rep] ^= (uint8_t)hh[0];   // keep the work observable
+            if (dt < best[impl]) best[impl] = dt;
+        }
+    return g_impl = best[1] < best[0] ? 1 : 0;
 }
 inline void compress(uint64_t h[8], const uint8_t *blk, uint64_t t0, uint64_t t1, bool last) {
     if (pick() == 1) compress_avx2(h, blk, t0, t1, last);

@@ -1,0 +1,11 @@
+import sys,time,hashlib,os
+sys.path.insert(0,'tests')
+from conftest import load_package
+pkg=load_package()
+L=pkg.load_library()
+data=os.urandom(256<<20)
+for impl in (0,1,0,1):
+    L.ptau_blake2b_implementation(impl)
+    t=time.time(); h=pkg.calculate_hash(data); dt=time.time()-t
+    print(impl, "  %.2f GB/s"%(len(data)/dt/1e9))
+t=time.time(); hashlib.blake2b(data).digest(); print("hashlib %.2f GB/s"%(len(data)/(time.time()-t)/1e9))
