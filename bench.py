@@ -119,7 +119,8 @@ def whole_chunk_extras(pkg, curve, power, log2n, dev):
     d = tempfile.mkdtemp(prefix="ptau_bench_", dir=base)
     f = lambda name: os.path.join(d, name)
     elems = n1 + 3 * n2 + 1
-    out = {"workload": "%s power %d chunk 0, chunk_size 2^%d: %d G1 + %d G2 elements; challenge %d B, response %d B; "
+    out = {"host_blake2b": {0: "portable", 1: "avx2"}[pkg.load_library().ptau_blake2b_implementation(-1)],
+           "workload": "%s power %d chunk 0, chunk_size 2^%d: %d G1 + %d G2 elements; challenge %d B, response %d B; "
                        "file-level entry points, files on %s" % (curve, power, log2n, n1 + 2 * n2, n2 + 1, prm.accumulator_size,
                                                                   prm.contribution_size, base or "the default tmp dir")}
     try:
