@@ -114,7 +114,11 @@ struct DeviceCtx {
     void *d_small = nullptr;                  // single-point results (MSM)
     void *msm_ws = nullptr;                   // bucket-MSM workspace
     size_t msm_cap = 0;
-    void *d_pair = nullptr;                   // pairing kernel: packed checks | results | GT values
+    // pairing kernel (K5): its own lock, stream and buffer — a launch is a handful of workgroups for ~50 ms, which must
+    // not hold up another lane's vector kernels (they run side by side on the device)
+    std::mutex pair_mu;
+    hipStream_t pair_stream = nullptr;
+    void *d_pair = nullptr;                   // packed checks | results | GT values
     size_t pair_cap = 0;
     size_t in_cap = 0, out_cap = 0;
     // side stream for the lone beta_g2 element of a chunk: its membership test is ONE thread's scalar multiplication
@@ -159,13 +163,13 @@ int ensure_ctx(int device, DeviceCtx *&c, const Err &err, bool side = false) {
     HIP_TRY(hipSetDevice(device));
     std::lock_guard<std::mutex> init_lk(g_init_mu);
     if (c->ready) return PTAU_OK;
-    hipStream_t st[3] = {nullptr, nullptr, nullptr};
+    hipStream_t st[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t evs[8] = {};
     void *bufs[4] = {nullptr, nullptr, nullptr, nullptr};
     const size_t buf_sz[4] = {sizeof(uint32_t) * (1 + ptau::SCALAR_TABLE_ENTRIES) * 24, 256, 4096, 16384};
     hipError_t e = hipSuccess;
     const char *what = "";
-    for (int i = 0; i < 3 && e == hipSuccess; i++) { e = hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking); what = "hipStreamCreateWithFlags"; }
+    for (int i = 0; i < 4 && e == hipSuccess; i++) { e = hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking); what = "hipStreamCreateWithFlags"; }
     for (int i = 0; i < 8 && e == hipSuccess; i++) { e = hipEventCreate(&evs[i]); what = "hipEventCreate"; }
     for (int i = 0; i < 4 && e == hipSuccess; i++) { e = hipMalloc(&bufs[i], buf_sz[i]); what = "hipMalloc"; }
     if (e != hipSuccess) {
@@ -177,6 +181,7 @@ int ensure_ctx(int device, DeviceCtx *&c, const Err &err, bool side = false) {
     c->stream = st[0];
     c->side_stream = st[1];
     c->copy_stream = st[2];
+    c->pair_stream = st[3];
     for (int i = 0; i < 6; i++) c->ev[i] = evs[i];
     c->cev[0] = evs[6];
     c->cev[1] = evs[7];
@@ -1497,17 +1502,17 @@ int ptau_check_same_ratio_batch(int curve, const uint8_t *checks, uint64_t n, in
     DeviceCtx *c;
     int rc = ensure_ctx(device, c, err);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(c->mu);
+    std::lock_guard<std::mutex> lk(c->pair_mu);
     HIP_TRY(hipSetDevice(device));
     const size_t in_bytes = n * po->check_bytes, gt_bytes = gt_out ? n * (size_t)po->K * po->n32 * 4 : 0;
     const size_t off_res = (in_bytes + 255) & ~(size_t)255, off_gt = off_res + ((n * sizeof(int) + 255) & ~(size_t)255);
     if ((rc = grow(c->d_pair, c->pair_cap, off_gt + gt_bytes + 256, err))) return rc;
     uint8_t *d = (uint8_t *)c->d_pair;
-    HIP_TRY(hipMemcpyAsync(d, checks, in_bytes, hipMemcpyHostToDevice, c->side_stream));
-    po->launch(c->side_stream, d, (int *)(d + off_res), gt_out ? (uint32_t *)(d + off_gt) : nullptr, (int)n);
-    HIP_TRY(hipMemcpyAsync(results, d + off_res, n * sizeof(int), hipMemcpyDeviceToHost, c->side_stream));
-    if (gt_out) HIP_TRY(hipMemcpyAsync(gt_out, d + off_gt, gt_bytes, hipMemcpyDeviceToHost, c->side_stream));
-    HIP_TRY(hipStreamSynchronize(c->side_stream));
+    HIP_TRY(hipMemcpyAsync(d, checks, in_bytes, hipMemcpyHostToDevice, c->pair_stream));
+    po->launch(c->pair_stream, d, (int *)(d + off_res), gt_out ? (uint32_t *)(d + off_gt) : nullptr, (int)n);
+    HIP_TRY(hipMemcpyAsync(results, d + off_res, n * sizeof(int), hipMemcpyDeviceToHost, c->pair_stream));
+    if (gt_out) HIP_TRY(hipMemcpyAsync(gt_out, d + off_gt, gt_bytes, hipMemcpyDeviceToHost, c->pair_stream));
+    HIP_TRY(hipStreamSynchronize(c->pair_stream));
     HIP_TRY(hipGetLastError());
     return PTAU_OK;
 }
