@@ -314,6 +314,11 @@ struct FpL {
             acc[0] += x >> LB;
             acc[H - 1] = recv;
         }
+        row_finish(acc, pm, out);
+    }
+    // second half of a product: the N-position row -> digits, fully reduced
+    PTAU_HD static void row_finish(const uint64_t (&acc)[H], const uint32_t (&pm)[H], uint32_t (&out)[H]) {
+        const bool hi = hi_lane();
         // carry-propagate both halves at once (carry-in 0), then fold the even lane's carry-out (< 2^36) into the odd
         // lane's two lowest digits
         uint32_t r[H];
@@ -356,6 +361,53 @@ struct FpL {
 #pragma unroll
         for (int j = 0; j < H; j++) out[j] = borrow ? r[j] : d[j];
     }
+    // Square: the cross terms between the two halves are computed once, doubled (odd lane, iterations i < H), and the
+    // high half's own square skips the products below its diagonal (iterations i >= H, where the even lane adds nothing):
+    // H (H - 1) / 2 fewer MAC slots per lane than the product, the same column values.
+    PTAU_HD static void row_sqr(const uint32_t (&a)[H], uint32_t (&out)[H]) {
+        const bool hi = hi_lane();
+        uint32_t pm[H], az[H];
+#pragma unroll
+        for (int j = 0; j < H; j++) {
+            pm[j] = hi ? P::MOD[H + j] : P::MOD[j];
+            az[j] = hi ? a[j] : 0u;        // the row of iterations i >= H: the even lane contributes nothing there
+        }
+        const uint32_t dbl_odd = hi ? 1u : 0u;
+        uint64_t acc[H];
+#pragma unroll
+        for (int j = 0; j < H; j++) acc[j] = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            if (i < H) {
+                // even lane: a_i * (low half), every j (both orders of a pair: no doubling); odd lane: 2 a_i * (high half)
+                const uint32_t ai = lane_bcast_even(a[i]) << dbl_odd;
+#pragma unroll
+                for (int j = 0; j < H; j++) mac64_vv(acc[j], ai, a[j]);
+            } else {
+                const int d = i - H;
+                const uint32_t ai = lane_bcast_odd(a[d]);
+                mac64_vv(acc[d], ai, az[d]);
+                const uint32_t ai2 = ai << 1;
+#pragma unroll
+                for (int j = d + 1; j < H; j++) mac64_vv(acc[j], ai2, az[j]);
+            }
+            // m from the even lane's position 0, broadcast to the pair
+            const uint32_t m = lane_bcast_even(((uint32_t)acc[0] * P::INV) & MASK);
+#pragma unroll
+            for (int j = 0; j < H; j++) mac64_vv(acc[j], m, pm[j]);
+            // Shift the row down one limb, the same code in both lanes: the lowest accumulator leaves its carry to the next
+            // one and its low 29 bits to the partner, whose top slot they become.  Even lane: those bits are zero by the
+            // choice of m, so the odd lane's top slot restarts at zero; odd lane: they are limb H of the row and arrive as
+            // the even lane's new top slot.
+            const uint64_t x = acc[0];
+            const uint32_t recv = lane_xchg((uint32_t)x & MASK);
+#pragma unroll
+            for (int j = 0; j + 1 < H; j++) acc[j] = acc[j + 1];
+            acc[0] += x >> LB;
+            acc[H - 1] = recv;
+        }
+        row_finish(acc, pm, out);
+    }
     // one out-of-line copy per field, register ABI (H limbs per operand in VGPRs)
     __device__ __noinline__ static VecH mul_vec(VecH a, VecH b) {
         uint32_t x[H], y[H], r[H];
@@ -382,7 +434,30 @@ struct FpL {
         return a;   // lane-split fields exist on the device only
 #endif
     }
-    PTAU_HD static FpL sqr(const FpL &a) { return mul(a, a); }
+    __device__ __noinline__ static VecH sqr_vec(VecH a) {
+        uint32_t x[H], r[H];
+#pragma unroll
+        for (int j = 0; j < H; j++) x[j] = a[j];
+        row_sqr(x, r);
+        VecH o;
+#pragma unroll
+        for (int j = 0; j < H; j++) o[j] = r[j];
+        return o;
+    }
+    PTAU_HD static FpL sqr(const FpL &a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        VecH x;
+#pragma unroll
+        for (int j = 0; j < H; j++) x[j] = a.l[j];
+        const VecH o = sqr_vec(x);
+        FpL r;
+#pragma unroll
+        for (int j = 0; j < H; j++) r.l[j] = o[j];
+        return r;
+#else
+        return a;
+#endif
+    }
 
     PTAU_HD static FpL mul_small(const FpL &a, int k) {
         if (k == 0) return zero();
