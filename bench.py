@@ -232,7 +232,7 @@ MAC_PEAK = 32.7e12        # measured v_mad_u64_u32 issue peak, lane-MACs/s chip-
 
 def macs_per_update(curve, group, endo):
     """32x32->64 multiply-accumulates of one prime-field G1-type update, from the formulas the kernel runs:
-    product 2 N^2, square N^2 + N (N + 1) / 2 (lane-split fields square with the product: 2 N^2); doubling 2M + 5S (a = 0) or
+    product 2 N^2, square N^2 + N (N + 1) / 2 (lane-split fields: 2 N^2 - H (H - 1), H = N / 2); doubling 2M + 5S (a = 0) or
     3M + 6S (+ a small a * Z^4 chain); table of 8 multiples by 7 mixed additions (7M + 4S); signed 4-bit windows (15/16 of
     the digits are non-zero); window additions: mixed (7M + 4S) on the common-Z table of the j = 0 curves (+ 51 products to
     rescale the table), full (11M + 5S) on the MNT curves.
@@ -241,7 +241,7 @@ def macs_per_update(curve, group, endo):
         return None
     n = FIELD_LIMBS[curve]
     m = 2 * n * n
-    sq = m if curve != "bls12_377" else n * n + n * (n + 1) // 2
+    sq = m - (n // 2) * (n // 2 - 1) if curve != "bls12_377" else n * n + n * (n + 1) // 2   # lane-split square: H (H - 1) / 2 fewer MACs per lane
     a_zero = curve in ("bls12_377", "bw6")
     dbl = 2 * m + 5 * sq if a_zero else 3 * m + 6 * sq
     madd = 7 * m + 4 * sq
