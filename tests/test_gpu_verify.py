@@ -455,3 +455,32 @@ def test_power_pairs_across_msm_slices(pkg):
     bad[o:o + 96], bad[o + 96:o + 192] = bad[o + 96:o + 192], bad[o:o + 96]
     a2, b2 = pkg.phase1_cli.power_pairs(name, 1, bytes(bad), n)
     assert pkg.phase1_cli.apply_powers(name, 1, a2, 1, 1, s, None, False, False) != b2
+
+
+def test_cold_start_from_several_threads(tmp_path):
+    """The FIRST ptau_* calls of a process arrive from three threads at once on one device (in-process lanes of the operator,
+    contribute.rs:467-492): context creation is serialised inside the library, every lane gets the right bytes."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    script = tmp_path / "cold.py"
+    script.write_text('''
+import sys, threading, hashlib
+sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+import torch; torch.cuda.is_available()
+from conftest import load_package
+pkg = load_package()
+gen = pkg.phase1_cli.generator("bls12_377", 1)
+n = 4096
+data = gen * n
+out = [None] * 3
+def lane(k):
+    out[k] = pkg.phase1_cli.apply_powers("bls12_377", 1, data, n, 17 * k, 0x1234567 + k)
+th = [threading.Thread(target=lane, args=(k,)) for k in range(3)]
+[t.start() for t in th]; [t.join() for t in th]
+again = [pkg.phase1_cli.apply_powers("bls12_377", 1, data, n, 17 * k, 0x1234567 + k) for k in range(3)]
+assert out == again and len(set(out)) == 3
+print("ok", hashlib.blake2b(b"".join(out)).hexdigest()[:16])
+''' % (ROOT, ROOT))
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stderr[-2000:]
