@@ -459,10 +459,83 @@ struct FpL {
 #endif
     }
 
+    // r - p when r >= p, for r < 2p given as digits (both lanes' chains at once, the borrow folded across)
+    PTAU_HD static void reduce_once(const uint32_t (&r)[H], const uint32_t (&pm)[H], uint32_t (&out)[H]) {
+        const bool hi = hi_lane();
+        uint32_t d[H];
+        int32_t cy = 0;
+#pragma unroll
+        for (int j = 0; j < H; j++) {
+            const int32_t v = (int32_t)r[j] - (int32_t)pm[j] + cy;
+            cy = v >> LB;
+            d[j] = (uint32_t)v & MASK;
+        }
+        const int32_t cy_in = (int32_t)lane_xchg((uint32_t)cy);
+        const int32_t top = cy + fold_carry(d, hi ? cy_in : 0);
+        const int32_t top_o = (int32_t)lane_xchg((uint32_t)top);
+        const bool borrow = (hi ? top : top_o) < 0;
+#pragma unroll
+        for (int j = 0; j < H; j++) out[j] = borrow ? r[j] : d[j];
+    }
+    // k * a for a small positive constant k (4 <= k <= 15), without the double-and-add chain of modular additions (each ~230
+    // instructions on a lane pair): the integer k a (one MAC per limb), a quotient estimate q from its top limbs against
+    // p's (q <= floor(k a / p) <= q + 2), k a - q p (one MAC per limb), two conditional subtractions.  The non-residue and
+    // curve-coefficient multiples of the extension fields (5, 11, 13, ...) are every third instruction of an Fq2 / Fq3 product.
+    PTAU_HD static FpL mul_small_fast(const FpL &a, unsigned k) {
+        constexpr int TL = (P::BITS - 1) / LB;   // the limb that holds p's top bits
+        static_assert(TL >= H && TL < N, "p's top limb must sit in the odd lane");
+        const bool hi = hi_lane();
+        uint32_t pm[H], v[H];
+#pragma unroll
+        for (int j = 0; j < H; j++) pm[j] = hi ? P::MOD[H + j] : P::MOD[j];
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < H; j++) {
+            const uint64_t acc = (uint64_t)a.l[j] * k + c;
+            v[j] = (uint32_t)acc & MASK;
+            c = acc >> LB;
+        }
+        const uint32_t c_even = lane_xchg((uint32_t)c);            // the even lane's carry-out enters the odd lane's digits
+        uint32_t ctop = (uint32_t)c;                                 // odd lane: bits above 29 N
+        ctop += (uint32_t)fold_carry(v, hi ? (int32_t)c_even : 0);
+        // quotient estimate in the odd lane from the top ~29-60 bits, broadcast to the pair
+        const uint64_t tv = (uint64_t)v[TL - H] | ((uint64_t)(TL + 1 < N ? v[TL + 1 - H < H ? TL + 1 - H : H - 1] : ctop) << LB);
+        constexpr uint64_t step = (uint64_t)P::MOD[TL] + 1u;
+        uint32_t q = 0;
+#pragma unroll
+        for (unsigned i = 1; i < 16; i++)
+            if (i < k) q += tv >= i * step ? 1u : 0u;
+        q = lane_bcast_odd(q);
+        // w = k a - q p  (signed chain; the bits above 29 N cancel: the result is below 3p)
+        uint32_t w[H];
+        int64_t cy = 0;
+#pragma unroll
+        for (int j = 0; j < H; j++) {
+            const int64_t acc = (int64_t)v[j] - (int64_t)((uint64_t)q * pm[j]) + cy;
+            w[j] = (uint32_t)acc & MASK;
+            cy = acc >> LB;
+        }
+        const int32_t cy_even = (int32_t)lane_xchg((uint32_t)(int32_t)cy);
+        (void)fold_carry(w, hi ? cy_even : 0);
+        uint32_t r1[H];
+        FpL r;
+        reduce_once(w, pm, r1);
+        reduce_once(r1, pm, r.l);
+        return r;
+    }
     PTAU_HD static FpL mul_small(const FpL &a, int k) {
         if (k == 0) return zero();
         bool ng = k < 0;
         unsigned uk = ng ? (unsigned)(-k) : (unsigned)k;
+        if (uk >= 16 && uk < 32) {   // e.g. the MNT4 twist's a = 26 = 2 * 13
+            FpL t = dbl(mul_small_fast(a, uk / 2));
+            if (uk & 1u) t = add(t, a);
+            return ng ? neg(t) : t;
+        }
+        if (uk >= 4 && uk < 16) {
+            const FpL t = mul_small_fast(a, uk);
+            return ng ? neg(t) : t;
+        }
         FpL acc = zero(), base = a;
         bool first = true;
         while (uk) {
