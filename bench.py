@@ -167,7 +167,8 @@ def whole_chunk_extras(pkg, curve, power, log2n, dev):
         # several in-process lanes on ONE GPU (the operator's --max-in-process-lane, contribute.rs:120-121,467-492): the
         # library serialises only the device section of a call, so one lane's BLAKE2b overlaps another lane's kernels
         import threading
-        for lanes in (2, 3):
+        Lb = pkg.load_library()
+        for lanes in (1, 2, 3):
             def lane_verify(k):
                 pkg.transform_pok_and_correctness(f("c0"), f("L%d.c.hash" % k), pkg.CheckForCorrectness.No, f("r0"), f("L%d.r.hash" % k),
                                                   pkg.CheckForCorrectness.OnlyNonZero, f("L%d.c1" % k), f("L%d.c1.hash" % k),
@@ -177,17 +178,19 @@ def whole_chunk_extras(pkg, curve, power, log2n, dev):
                                                  verified, prm, seed1, device=dev)
             for name, fn, outs in (("verify", lane_verify, ("L%d.c1",)), ("contribute", lane_contribute, ("L%d.r1",))):
                 th = [threading.Thread(target=fn, args=(k,)) for k in range(lanes)]
+                busy0 = Lb.ptau_device_busy_ms(dev)
                 t0 = time.perf_counter()
                 for t in th:
                     t.start()
                 for t in th:
                     t.join()
                 dtl = time.perf_counter() - t0
+                busy = (Lb.ptau_device_busy_ms(dev) - busy0) / 1e3 / dtl
                 for k in range(lanes):
                     for o in outs:
                         assert os.path.getsize(f(o % k)) > 0
                         os.remove(f(o % k))
-                out.setdefault("lanes", {})["%s_%d_lanes" % (name, lanes)] = {"seconds": dtl, "chunks_per_s": lanes / dtl}
+                out.setdefault("lanes", {})["%s_%d_lanes" % (name, lanes)] = {"seconds": dtl, "chunks_per_s": lanes / dtl, "gpu_busy": busy}
         # whole-transcript tail (BASELINE configs[4]: verify_transcript's combine + transform_ratios): the round's second
         # chunk (tauG1 only, 2^n - 1 elements) contributed with the same key, both responses combined, ratio checks run
         prm1 = pkg.Phase1Parameters.new_chunk(curve, 0, 1, n, 0, log2n, n)

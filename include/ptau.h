@@ -294,6 +294,10 @@ int ptau_contribute_file_seeded(const ptau_params *p, const char *challenge_path
                                 const char *response_path, const char *response_hash_path, const uint8_t *seed, size_t seed_len,
                                 int check_input, int batch_exp_mode, int device, char *err, size_t err_len);
 
+/* Cumulative kernel time (HIP events, ms) of every call on `device` since the library was loaded: the numerator of a
+ * GPU-busy fraction over a wall-clock interval (several in-process lanes).  < 0 on a bad ordinal. */
+double ptau_device_busy_ms(int device);
+
 /* Timings of the most recent compute call on `device`. */
 int ptau_last_timing(int device, ptau_timing *out);
 

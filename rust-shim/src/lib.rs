@@ -82,6 +82,7 @@ extern "C" {
     pub fn ptau_key_generation(curve: c_int, seed: *const u8, seed_len: usize, digest: *const u8, tau: *mut u64, alpha: *mut u64, beta: *mut u64, public_key: *mut u8, public_key_len: usize, err: *mut c_char, err_len: usize) -> c_int;
     pub fn ptau_compute_g2_s(curve: c_int, digest: *const u8, public_key: *const u8, public_key_len: usize, g2_s_out: *mut u8, err: *mut c_char, err_len: usize) -> c_int;
     pub fn ptau_last_timing(device: c_int, out: *mut PtauTiming) -> c_int;
+    pub fn ptau_device_busy_ms(device: c_int) -> f64;
 }
 
 /// The selectors the operator parses from its CLI (`contribute.rs:38-43, 134-145`), with the C ABI's values.

@@ -22,7 +22,7 @@ DECLARED_SYMBOLS = [
     "ptau_transform_pok_and_correctness_file", "ptau_msm", "ptau_power_pairs", "ptau_check_same_ratio", "ptau_new_challenge", "ptau_new_challenge_file",
     "ptau_combine", "ptau_transform_ratios", "ptau_verify_pok", "ptau_new_challenge_with_generators", "ptau_generator",
     "ptau_chacha20_rng_words", "ptau_key_generation", "ptau_private_key_from_seed", "ptau_compute_g2_s", "ptau_contribute_file_seeded",
-    "ptau_check_same_ratio_batch", "ptau_blake2b_implementation",
+    "ptau_check_same_ratio_batch", "ptau_blake2b_implementation", "ptau_device_busy_ms",
 ]
 
 
@@ -95,6 +95,8 @@ def load_library():
     L.ptau_compute_g2_s.argtypes = [i, u8p, u8p, sz, u8p, cp, sz]
     L.ptau_contribute_file_seeded.argtypes = [ctypes.POINTER(ptau_params), cp, cp, cp, cp, u8p, sz, i, i, i, cp, sz]
     L.ptau_blake2b_implementation.argtypes = [i]
+    L.ptau_device_busy_ms.argtypes = [i]
+    L.ptau_device_busy_ms.restype = ctypes.c_double
     L.ptau_check_same_ratio_batch.argtypes = [i, u8p, u64, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint32), i, cp, sz]
     _lib = L
     return L

@@ -140,6 +140,7 @@ struct DeviceCtx {
         size_t mark = 0;
     } pending;
     ptau_timing timing = {};
+    double busy_ms = 0;   // kernel time since the library was loaded, every call on this device (under mu)
 };
 DeviceCtx g_ctx[MAX_DEVICES];
 // second context per device (own stream and small buffers) for the lone beta_g2 element of a contribution: its update is
@@ -264,6 +265,7 @@ int run_apply_powers_dev(DeviceCtx *c, int curve, int group, const GroupOps *ops
         c->timing.scalar_mul_ms += a;
         c->timing.normalize_ms += b;
         c->timing.kernel_ms += a + b;
+        c->busy_ms += a + b;
         c->timing.points += m;
         if ((rc = errbits_to_code(bits, err))) return rc;
     }
@@ -436,6 +438,7 @@ int run_msm_bucket_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, i
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
     c->timing.kernel_ms += ms;
+    c->busy_ms += ms;
     c->timing.msm_ms += ms;
     c->timing.points += n * nsum;
     return errbits_to_code(bits, err);
@@ -490,6 +493,7 @@ int run_msm_naive_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, in
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
     c->timing.kernel_ms += ms;
+    c->busy_ms += ms;
     c->timing.msm_ms += ms;
     c->timing.points += n;
     return errbits_to_code(bits, err);
@@ -562,6 +566,7 @@ int run_subgroup_check_dev(DeviceCtx *c, int curve, int group, const GroupOps *o
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
     c->timing.kernel_ms += ms;
+    c->busy_ms += ms;
     c->timing.subgroup_ms += ms;
     c->timing.points += n;
     return errbits_to_code(bits, err);
@@ -617,10 +622,12 @@ int run_verify_vector(DeviceCtx *c, int curve, int group, const GroupOps *ops, c
     c->timing.h2d_ms += ms;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[4], c->ev[5]));
     c->timing.kernel_ms += ms;
+    c->busy_ms += ms;
     c->timing.decompress_ms += ms;
     if (want_subgroup) {
         HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
         c->timing.kernel_ms += ms;
+        c->busy_ms += ms;
         c->timing.subgroup_ms += ms;
     }
     c->timing.points += n;
@@ -820,6 +827,12 @@ int ptau_params_sizes(const ptau_params *p, ptau_sizes *out) {
     out->accumulator_size = 64 + n1 * g1->uncomp + n2 * (g2->uncomp + 2ull * g1->uncomp) + g2->uncomp;
     out->contribution_size = 64 + n1 * g1->comp + n2 * (g2->comp + 2ull * g1->comp) + g2->comp + out->public_key_size;
     return PTAU_OK;
+}
+
+double ptau_device_busy_ms(int device) {
+    if (device < 0 || device >= MAX_DEVICES) return -1.0;
+    std::lock_guard<std::mutex> lk(g_ctx[device].mu);
+    return g_ctx[device].busy_ms + g_side_ctx[device].busy_ms;
 }
 
 int ptau_last_timing(int device, ptau_timing *out) {
@@ -1107,6 +1120,7 @@ int run_check_input_vector(DeviceCtx *c, int curve, int group, const GroupOps *o
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
         c->timing.kernel_ms += ms;
+        c->busy_ms += ms;
         c->timing.subgroup_ms += ms;
     }
     c->timing.points += n;

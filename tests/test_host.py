@@ -268,7 +268,7 @@ def test_rust_shim_declarations_match_the_header():
     hdr = open(os.path.join(ROOT, "include", "ptau.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     c_funcs = {}
-    for m in re.finditer(r"\b(?:int|void|const char \*)\s*(ptau_\w+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
+    for m in re.finditer(r"\b(?:int|void|double|const char \*)\s*(ptau_\w+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
         args = m.group(2).strip()
         c_funcs[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
     rs = open(os.path.join(ROOT, "rust-shim", "src", "lib.rs")).read()
