@@ -24,28 +24,31 @@ constexpr uint8_t SIGMA[12][16] = {
 
 inline uint64_t rotr(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
 
-void compress_portable(uint64_t h[8], const uint8_t *blk, uint64_t t0, uint64_t t1, bool last) {
-    uint64_t m[16], v[16];
-    memcpy(m, blk, 128);
-    for (int i = 0; i < 8; i++) { v[i] = h[i]; v[i + 8] = IV[i]; }
-    v[12] ^= t0;
-    v[13] ^= t1;
-    if (last) v[14] = ~v[14];
-    auto G = [&](int a, int b, int c, int d, uint64_t x, uint64_t y) {
-        v[a] += v[b] + x; v[d] = rotr(v[d] ^ v[a], 32);
-        v[c] += v[d];     v[b] = rotr(v[b] ^ v[c], 24);
-        v[a] += v[b] + y; v[d] = rotr(v[d] ^ v[a], 16);
-        v[c] += v[d];     v[b] = rotr(v[b] ^ v[c], 63);
-    };
-    for (int r = 0; r < 12; r++) {
-        const uint8_t *s = SIGMA[r];
-        G(0, 4, 8, 12, m[s[0]], m[s[1]]);   G(1, 5, 9, 13, m[s[2]], m[s[3]]);
-        G(2, 6, 10, 14, m[s[4]], m[s[5]]);  G(3, 7, 11, 15, m[s[6]], m[s[7]]);
-        G(0, 5, 10, 15, m[s[8]], m[s[9]]);  G(1, 6, 11, 12, m[s[10]], m[s[11]]);
-        G(2, 7, 8, 13, m[s[12]], m[s[13]]); G(3, 4, 9, 14, m[s[14]], m[s[15]]);
-    }
-    for (int i = 0; i < 8; i++) h[i] ^= v[i] ^ v[i + 8];
-}
+#define PTAU_B2_SCALAR_BODY \
+    uint64_t m[16], v[16]; \
+    memcpy(m, blk, 128); \
+    for (int i = 0; i < 8; i++) { v[i] = h[i]; v[i + 8] = IV[i]; } \
+    v[12] ^= t0; \
+    v[13] ^= t1; \
+    if (last) v[14] = ~v[14]; \
+    auto G = [&](int a, int b, int c, int d, uint64_t x, uint64_t y) { \
+        v[a] += v[b] + x; v[d] = rotr(v[d] ^ v[a], 32); \
+        v[c] += v[d];     v[b] = rotr(v[b] ^ v[c], 24); \
+        v[a] += v[b] + y; v[d] = rotr(v[d] ^ v[a], 16); \
+        v[c] += v[d];     v[b] = rotr(v[b] ^ v[c], 63); \
+    }; \
+    for (int r = 0; r < 12; r++) { \
+        const uint8_t *s = SIGMA[r]; \
+        G(0, 4, 8, 12, m[s[0]], m[s[1]]);   G(1, 5, 9, 13, m[s[2]], m[s[3]]); \
+        G(2, 6, 10, 14, m[s[4]], m[s[5]]);  G(3, 7, 11, 15, m[s[6]], m[s[7]]); \
+        G(0, 5, 10, 15, m[s[8]], m[s[9]]);  G(1, 6, 11, 12, m[s[10]], m[s[11]]); \
+        G(2, 7, 8, 13, m[s[12]], m[s[13]]); G(3, 4, 9, 14, m[s[14]], m[s[15]]); \
+    } \
+    for (int i = 0; i < 8; i++) h[i] ^= v[i] ^ v[i + 8]; \
+
+void compress_portable(uint64_t h[8], const uint8_t *blk, uint64_t t0, uint64_t t1, bool last) { PTAU_B2_SCALAR_BODY }
+// the same source compiled for BMI2 (rorx: rotate without destroying the source register)
+__attribute__((target("bmi2"))) void compress_bmi2(uint64_t h[8], const uint8_t *blk, uint64_t t0, uint64_t t1, bool last) { PTAU_B2_SCALAR_BODY }
 
 // the four G functions of a column (then diagonal) step side by side: rows a, b, c, d of the state in one 256-bit register each
 __attribute__((target("avx2"))) void compress_avx2(uint64_t h[8], const uint8_t *blk, uint64_t t0, uint64_t t1, bool last) {
@@ -96,26 +99,33 @@ __attribute__((target("avx2"))) void compress_avx2(uint64_t h[8], const uint8_t 
 int g_impl = -1;
 int pick() {
     if (g_impl >= 0) return g_impl;
-    if (!__builtin_cpu_supports("avx2")) return g_impl = 0;
+    const bool have[3] = {true, (bool)__builtin_cpu_supports("avx2"), (bool)__builtin_cpu_supports("bmi2")};
     static uint8_t probe[128];
-    double best[2] = {1e30, 1e30};
+    double best[3] = {1e30, 1e30, 1e30};
     for (int rep = 0; rep < 3; rep++)
-        for (int impl = 0; impl < 2; impl++) {
+        for (int impl = 0; impl < 3; impl++) {
+            if (!have[impl]) continue;
             uint64_t hh[8];
             memcpy(hh, IV, sizeof hh);
             const auto t0 = std::chrono::steady_clock::now();
             for (int i = 0; i < 4096; i++) {
-                if (impl) compress_avx2(hh, probe, 128ull * i, 0, false);
+                if (impl == 1) compress_avx2(hh, probe, 128ull * i, 0, false);
+                else if (impl == 2) compress_bmi2(hh, probe, 128ull * i, 0, false);
                 else compress_portable(hh, probe, 128ull * i, 0, false);
             }
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             probe[rep] ^= (uint8_t)hh[0];   // keep the work observable
             if (dt < best[impl]) best[impl] = dt;
         }
-    return g_impl = best[1] < best[0] ? 1 : 0;
+    g_impl = 0;
+    for (int impl = 1; impl < 3; impl++)
+        if (best[impl] < best[g_impl]) g_impl = impl;
+    return g_impl;
 }
 inline void compress(uint64_t h[8], const uint8_t *blk, uint64_t t0, uint64_t t1, bool last) {
-    if (pick() == 1) compress_avx2(h, blk, t0, t1, last);
+    const int impl = pick();
+    if (impl == 1) compress_avx2(h, blk, t0, t1, last);
+    else if (impl == 2) compress_bmi2(h, blk, t0, t1, last);
     else compress_portable(h, blk, t0, t1, last);
 }
 
@@ -124,6 +134,7 @@ inline void compress(uint64_t h[8], const uint8_t *blk, uint64_t t0, uint64_t t1
 int blake2b_implementation(int force) {
     if (force == 0) g_impl = 0;
     else if (force == 1 && __builtin_cpu_supports("avx2")) g_impl = 1;
+    else if (force == 2 && __builtin_cpu_supports("bmi2")) g_impl = 2;
     return pick();
 }
 
