@@ -544,8 +544,12 @@ int enqueue_subgroup_kernels(DeviceCtx *c, int curve, int group, const GroupOps 
             int rc;
             if ((rc = grow(c->scratch, c->scratch_cap, m * ops->jac_bytes, err))) return rc;
             if ((rc = grow(c->wtab, c->wtab_cap, m * ptau::WINDOW_ENTRIES * ops->jac_bytes, err))) return rc;
-            ops->window_scalar_mul(c->stream, d_in + off * isz, cin, c->scratch, c->wtab, m,
-                                   ptau::ScalarSource{ptau::SCALAR_FIXED, c->d_table, 0, 0, 0}, 0, /*use_glv=*/0, c->d_err);
+            if (ops->subgroup_via_glv && use_endo_subgroup())   // [a]P + [b]phi(P) == O, |a|, |b| ~ sqrt(r): half the doublings, exact
+                ops->window_scalar_mul(c->stream, d_in + off * isz, cin, c->scratch, c->wtab, m,
+                                       ptau::ScalarSource{ptau::SCALAR_SUBGROUP_ENDO, nullptr, 0, 0, 0}, 0, /*use_glv=*/1, c->d_err);
+            else
+                ops->window_scalar_mul(c->stream, d_in + off * isz, cin, c->scratch, c->wtab, m,
+                                       ptau::ScalarSource{ptau::SCALAR_FIXED, c->d_table, 0, 0, 0}, 0, /*use_glv=*/0, c->d_err);
             ops->expect_infinity(c->stream, c->scratch, m, c->d_err);
         }
     }
@@ -663,8 +667,12 @@ int enqueue_single_side(DeviceCtx *c, int curve, int group, const GroupOps *ops,
             ops->on_curve(c->side_stream, b + SB_OUT, 1, d_err);
             if (!cofactor_is_one(curve, group)) {
                 HIP_TRY(hipMemcpyAsync(b + SB_ORDER, ops->group_order, sizeof(uint32_t) * ops->fr_limbs32, hipMemcpyHostToDevice, c->side_stream));
-                ops->window_scalar_mul(c->side_stream, b + SB_OUT, 0, b + SB_SCRATCH, b + SB_SCRATCH + ops->jac_bytes, 1,
-                                       ptau::ScalarSource{ptau::SCALAR_FIXED, (const uint32_t *)(b + SB_ORDER), 0, 0, 0}, 0, /*use_glv=*/0, d_err);
+                if (ops->subgroup_via_glv && use_endo_subgroup())
+                    ops->window_scalar_mul(c->side_stream, b + SB_OUT, 0, b + SB_SCRATCH, b + SB_SCRATCH + ops->jac_bytes, 1,
+                                           ptau::ScalarSource{ptau::SCALAR_SUBGROUP_ENDO, nullptr, 0, 0, 0}, 0, /*use_glv=*/1, d_err);
+                else
+                    ops->window_scalar_mul(c->side_stream, b + SB_OUT, 0, b + SB_SCRATCH, b + SB_SCRATCH + ops->jac_bytes, 1,
+                                           ptau::ScalarSource{ptau::SCALAR_FIXED, (const uint32_t *)(b + SB_ORDER), 0, 0, 0}, 0, /*use_glv=*/0, d_err);
                 ops->expect_infinity(c->side_stream, b + SB_SCRATCH, 1, d_err);
             }
         }

@@ -275,6 +275,21 @@ def main():
             s.append("  static constexpr uint32_t GLV2_G1[7] = {%s};" % limbs(g1, 7, 32))
             s.append("  static constexpr uint32_t GLV2_G2[7] = {%s};" % limbs(g2, 7, 32))
             s.append("  static constexpr int GLV2_E11 = %d, GLV2_E12 = %d, GLV2_E21 = %d, GLV2_E22 = %d;" % (e11, e12, e21, e22))
+            # Subgroup membership through the endomorphism: the lattice {(a, b): a + b LAMBDA = 0 mod r} is the prime ideal
+            # (r, phi - LAMBDA) of Z[phi] (phi^2 + phi + 1 = 0), generated by an element of norm a^2 - a b + b^2 = r: the
+            # endomorphism a + b phi then has degree r and its kernel — r points, containing the order-r subgroup on which
+            # phi = LAMBDA — IS that subgroup.  So  P in G  <=>  [a]P + [b]phi(P) == O  for ANY curve point P, with
+            # |a|, |b| ~ sqrt(r): half the doublings of [r]P == O and the same accept / reject set.
+            sub = None
+            for (va, vb) in ((a1, b1), (a2, b2), (a1 + a2, b1 + b2), (a1 - a2, b1 - b2)):
+                if va * va - va * vb + vb * vb == rr:
+                    sub = (va, vb)
+                    break
+            assert sub is not None and (sub[0] + sub[1] * lam) % rr == 0, "no norm-r lattice vector among the reduced basis"
+            assert abs(sub[0]) < 1 << 191 and abs(sub[1]) < 1 << 191
+            s.append("  static constexpr uint32_t SUB_A[6] = {%s};" % limbs(abs(sub[0]), 6, 32))
+            s.append("  static constexpr uint32_t SUB_B[6] = {%s};" % limbs(abs(sub[1]), 6, 32))
+            s.append("  static constexpr bool SUB_NEG_A = %s, SUB_NEG_B = %s;" % ("true" if sub[0] < 0 else "false", "true" if sub[1] < 0 else "false"))
         if glv:
             # phi(x, y) = (BETA x, y) = LAMBDA * (x, y) on the prime-order subgroup; k = k1 + k2*LAMBDA with
             # k2 = floor(k / LAMBDA), both below 2^127.  GLV_M = floor(2^256 / LAMBDA) for the reciprocal division.

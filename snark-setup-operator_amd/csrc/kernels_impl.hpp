@@ -175,7 +175,9 @@ scalar_mul_kernel(const uint8_t *__restrict__ in, int compressed_in, typename G:
 // Digits: d_w = nibble_w(k + 0x88..8) - 8 in [-8, 7], so any digit is available MSB-first without a
 // carry pass.  Table layout is entry-major, table[e * n + i], so lanes holding the same digit coalesce.
 // Where a thread's scalar comes from.
-enum : int { SCALAR_TAU_TABLE = 0, SCALAR_FIXED = 1, SCALAR_ARRAY = 2, SCALAR_PRF = 3 };
+// SCALAR_SUBGROUP_ENDO: no scalar at all — the two fixed half-length multipliers (a, b) of the endomorphism membership test
+// [a]P + [b]phi(P) == O (lattice-GLV curves: BW6-761; gen_constants.py SUB_A / SUB_B), through the GLV window loop
+enum : int { SCALAR_TAU_TABLE = 0, SCALAR_FIXED = 1, SCALAR_ARRAY = 2, SCALAR_PRF = 3, SCALAR_SUBGROUP_ENDO = 4 };
 struct ScalarSource {
     int mode;
     const uint32_t *ptr;      // TAU_TABLE: the tau^(2^k) table; FIXED: NL canonical limbs; ARRAY: n x NL canonical limbs
@@ -535,7 +537,12 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
         }
     };
     uint32_t k[NL];
-    thread_scalar<Fr>(src, i, k);
+    if (src.mode != SCALAR_SUBGROUP_ENDO) {
+        thread_scalar<Fr>(src, i, k);
+    } else {
+#pragma unroll
+        for (int j = 0; j < NL; j++) k[j] = 0;
+    }
     using Cfg = typename J::CfgT;
     if constexpr (Cfg::GLV_KIND != 0) {
         if (use_glv) {
@@ -544,8 +551,18 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
             constexpr int HL = Cfg::GLV_KIND == 1 ? 4 : 6;
             uint32_t kk[2][HL];
             bool ng[2] = {false, false};
-            if constexpr (Cfg::GLV_KIND == 1) glv_decompose<Cfg>(k, kk[0], kk[1]);
-            else glv2_decompose<Cfg>(k, kk[0], kk[1], ng[0], ng[1]);
+            if constexpr (Cfg::GLV_KIND == 1) {
+                glv_decompose<Cfg>(k, kk[0], kk[1]);
+            } else {
+                if (src.mode == SCALAR_SUBGROUP_ENDO) {   // membership test: fixed (a, b) with a + b lambda = 0 mod r, norm r
+#pragma unroll
+                    for (int j = 0; j < HL; j++) { kk[0][j] = Cfg::SUB_A[j]; kk[1][j] = Cfg::SUB_B[j]; }
+                    ng[0] = Cfg::SUB_NEG_A;
+                    ng[1] = Cfg::SUB_NEG_B;
+                } else {
+                    glv2_decompose<Cfg>(k, kk[0], kk[1], ng[0], ng[1]);
+                }
+            }
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 uint32_t c2 = 0;
@@ -1148,6 +1165,8 @@ struct GroupOps {
     void (*expect_infinity)(hipStream_t, const void *scratch, uint64_t n, int *err);
     // endomorphism membership test incl. the on-curve test of uncompressed input; NULL where the group has none
     void (*endo_subgroup)(hipStream_t, const uint8_t *in, int cin, uint64_t n, int *err);
+    // membership through K1's GLV loop with the fixed pair (a, b), [a]P + [b]phi(P) == O (SCALAR_SUBGROUP_ENDO): BW6-761
+    bool subgroup_via_glv;
     void (*decompress)(hipStream_t, const uint8_t *in, uint8_t *out, uint64_t n, int check_nonzero, int *err);
     const uint32_t *group_order;   // r, canonical 32-bit limbs (fr_limbs32)
     // O(1) host-side decompression for the pairing tail (a handful of public-key / head elements)
@@ -1318,6 +1337,7 @@ struct Launch {
         o.normalize = normalize;
         o.expect_infinity = expect_infinity;
         o.endo_subgroup = G::J::CfgT::ENDO_KIND != 0 ? endo_subgroup : nullptr;
+        o.subgroup_via_glv = G::J::CfgT::GLV_KIND == 2;
         o.decompress = decompress;
         o.group_order = Fr::Params::MOD;
         o.decompress_host = decompress_host;

@@ -113,6 +113,17 @@ static int run(const std::string &op, uint64_t n, uint64_t start, int cin, int c
         out.resize(n);
         if constexpr (G::J::CfgT::ENDO_KIND != 0) {
             for (uint64_t i = 0; i < n; i++) out[i] = (uint8_t)endo_subgroup_thread<G>(in.data(), cin, i);
+        } else if constexpr (G::J::CfgT::GLV_KIND == 2) {
+            // lattice-GLV curves (BW6-761): [a]P + [b]phi(P) == O through K1's GLV loop (SCALAR_SUBGROUP_ENDO), after the
+            // on-curve test of an uncompressed encoding — as capi.hip's enqueue_subgroup_kernels does
+            std::vector<typename G::J> scratch(n), wtab(8 * n);
+            const ScalarSource src{SCALAR_SUBGROUP_ENDO, nullptr, 0, 0, 0};
+            for (uint64_t i = 0; i < n; i++) {
+                int b = cin ? 0 : on_curve_thread<G>(in.data(), i);
+                b |= window_scalar_mul_thread<G>(in.data(), cin, scratch.data(), wtab.data(), n, i, src, 0, /*use_glv=*/1);
+                if (!b && !scratch[i].Z.is_zero()) b |= ERRBIT_NOT_IN_SUBGROUP;
+                out[i] = (uint8_t)b;
+            }
         } else {
             return 4;
         }

@@ -153,18 +153,20 @@ def test_bucket_msm_bodies_on_host(name, group, n, c, cref):
     assert r.returncode == 0 and r.stdout == exp_a + exp_b
 
 
-@pytest.mark.parametrize("group", [1, 2])
-def test_endomorphism_subgroup_test_on_host(group):
-    """BLS12-377 membership test through the endomorphism (phi on G1, psi on G2): the kernel body, run on the CPU,
-    accepts exactly the points the oracle's [r]P == O accepts — subgroup points, cofactor-only points, mixed points,
-    small-order components, the point at infinity — for compressed and uncompressed encodings."""
+@pytest.mark.parametrize("name,group", [("bls12_377", 1), ("bls12_377", 2), ("bw6", 1), ("bw6", 2)])
+def test_endomorphism_subgroup_test_on_host(name, group):
+    """Membership tests through an endomorphism — BLS12-377: phi on G1, psi on G2 (eprint 2021/1130); BW6-761:
+    [a]P + [b]phi(P) == O for the norm-r element a + b phi of Z[phi] — the kernel bodies, run on the CPU, accept exactly
+    the points the oracle's [r]P == O accepts: subgroup points, cofactor-only points, mixed points, small-order
+    components, the point at infinity, for compressed and uncompressed encodings."""
     import random
     from oracle.pyref import serde
     from oracle.pyref.ec import Group
     exe = os.path.join(ROOT, "tests", "native", "host_emul")
     if not os.path.exists(exe):
         pytest.skip("host_emul not built")
-    cv = CURVES["bls12_377"]
+    cv = CURVES[name]
+    cid = str(CURVE_NAMES.index(name))
     G = Group(cv, group)
     F = G.F
     rng = random.Random(group)
@@ -179,7 +181,7 @@ def test_endomorphism_subgroup_test_on_host(group):
     for _ in range(3 if group == 1 else 2):
         P = rand_point()
         pts += [P, G.mul(P, cv.r), G.add(G.mul(P, cv.r), G.gen)]
-    if group == 1:   # components of small order (the G1 cofactor is 2^92 * 3 * ...): r * (h / f) * P
+    if group == 1 and name == "bls12_377":   # components of small order (the G1 cofactor is 2^92 * 3 * ...): r * (h / f) * P
         h = 0x170b5d44300000000000000000000000
         P = rand_point()
         pts += [G.mul(P, cv.r * (h // f)) for f in (2, 3, 4)]
@@ -187,13 +189,13 @@ def test_endomorphism_subgroup_test_on_host(group):
     assert 8 in expect and 0 in expect
     for comp in (0, 1):
         data = serde.write_batch(G, pts, bool(comp))
-        r = subprocess.run([exe, "subgroup", "0", str(group), str(len(pts)), "0", str(comp), "0", "0", "-"], input=data,
+        r = subprocess.run([exe, "subgroup", cid, str(group), str(len(pts)), "0", str(comp), "0", "0", "-"], input=data,
                            capture_output=True)
         assert r.returncode == 0 and r.stdout == expect
     # uncompressed point off the curve
     x, y = pts[0]
     off = serde.write_point(G, (x, F.add(y, F.one())), False)
-    r = subprocess.run([exe, "subgroup", "0", str(group), "1", "0", "0", "0", "0", "-"], input=off, capture_output=True)
+    r = subprocess.run([exe, "subgroup", cid, str(group), "1", "0", "0", "0", "0", "-"], input=off, capture_output=True)
     assert r.stdout == bytes([2])
 
 
