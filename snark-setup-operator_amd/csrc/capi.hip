@@ -531,7 +531,9 @@ int enqueue_subgroup_kernels(DeviceCtx *c, int curve, int group, const GroupOps 
     const int isz = cin ? ops->comp : ops->uncomp;
     const uint64_t launch_cap =
         std::max<uint64_t>(256, std::min(MAX_LAUNCH_POINTS, MAX_WINDOW_TABLE_BYTES / (ptau::WINDOW_ENTRIES * ops->jac_bytes)));
-    HIP_TRY(hipMemcpyAsync(c->d_table, ops->group_order, sizeof(uint32_t) * ops->fr_limbs32, hipMemcpyHostToDevice, c->stream));
+    const bool via_psi = ops->psi_check && use_endo_subgroup();   // MNT twists: psi(P) == [t - 1]P, a half-length fixed scalar
+    HIP_TRY(hipMemcpyAsync(c->d_table, via_psi ? ops->psi_scalar : ops->group_order, sizeof(uint32_t) * ops->fr_limbs32,
+                           hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     if (ops->endo_subgroup && use_endo_subgroup()) {
         ops->endo_subgroup(c->stream, d_in, cin, n, c->d_err);   // on-curve test included
@@ -550,7 +552,8 @@ int enqueue_subgroup_kernels(DeviceCtx *c, int curve, int group, const GroupOps 
             else
                 ops->window_scalar_mul(c->stream, d_in + off * isz, cin, c->scratch, c->wtab, m,
                                        ptau::ScalarSource{ptau::SCALAR_FIXED, c->d_table, 0, 0, 0}, 0, /*use_glv=*/0, c->d_err);
-            ops->expect_infinity(c->stream, c->scratch, m, c->d_err);
+            if (via_psi) ops->psi_check(c->stream, d_in + off * isz, cin, c->scratch, m, c->d_err);
+            else ops->expect_infinity(c->stream, c->scratch, m, c->d_err);
         }
     }
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
@@ -666,14 +669,17 @@ int enqueue_single_side(DeviceCtx *c, int curve, int group, const GroupOps *ops,
         } else {
             ops->on_curve(c->side_stream, b + SB_OUT, 1, d_err);
             if (!cofactor_is_one(curve, group)) {
-                HIP_TRY(hipMemcpyAsync(b + SB_ORDER, ops->group_order, sizeof(uint32_t) * ops->fr_limbs32, hipMemcpyHostToDevice, c->side_stream));
+                const bool via_psi = ops->psi_check != nullptr && use_endo_subgroup();
+                HIP_TRY(hipMemcpyAsync(b + SB_ORDER, via_psi ? ops->psi_scalar : ops->group_order, sizeof(uint32_t) * ops->fr_limbs32,
+                                       hipMemcpyHostToDevice, c->side_stream));
                 if (ops->subgroup_via_glv && use_endo_subgroup())
                     ops->window_scalar_mul(c->side_stream, b + SB_OUT, 0, b + SB_SCRATCH, b + SB_SCRATCH + ops->jac_bytes, 1,
                                            ptau::ScalarSource{ptau::SCALAR_SUBGROUP_ENDO, nullptr, 0, 0, 0}, 0, /*use_glv=*/1, d_err);
                 else
                     ops->window_scalar_mul(c->side_stream, b + SB_OUT, 0, b + SB_SCRATCH, b + SB_SCRATCH + ops->jac_bytes, 1,
                                            ptau::ScalarSource{ptau::SCALAR_FIXED, (const uint32_t *)(b + SB_ORDER), 0, 0, 0}, 0, /*use_glv=*/0, d_err);
-                ops->expect_infinity(c->side_stream, b + SB_SCRATCH, 1, d_err);
+                if (via_psi) ops->psi_check(c->side_stream, b + SB_OUT, 0, b + SB_SCRATCH, 1, d_err);
+                else ops->expect_infinity(c->side_stream, b + SB_SCRATCH, 1, d_err);
             }
         }
     }

@@ -256,6 +256,7 @@ struct Fp3 {
         return r;
     }
     PTAU_HD static Fp3 sqr(const Fp3 &a) { return mul(a, a); }
+    PTAU_HD static Fp3 mul_base(const Fp3 &a, const F &k) { return {F::mul(a.c0, k), F::mul(a.c1, k), F::mul(a.c2, k)}; }
     PTAU_HD static Fp3 make(const F &c0, const F &c1, const F &c2) { return {c0, c1, c2}; }
     static constexpr int LANES = F::LANES;
     __host__ __device__ __noinline__ static Fp3 inverse(const Fp3 &a) {

@@ -222,7 +222,7 @@ def main():
     out.append("using Mnt4Fr = Mnt6Fq;")
     out.append("using Mnt6Fr = Mnt4Fq;")
 
-    def coeffs(cname, fname, deg, a, b, nr, glv=None, endo=None, glv2=None, cofactor=1):
+    def coeffs(cname, fname, deg, a, b, nr, glv=None, endo=None, glv2=None, cofactor=1, psi=None):
         global _LB
         p, n, R, _LB = fields[fname]
         s = ["struct %s {" % cname]
@@ -243,6 +243,17 @@ def main():
                     rows.append("{%s}" % limbs(pow(endo[2], j, p) * R % p, n))
                     rows.append("{%s}" % limbs(pow(endo[3], j, p) * R % p, n))
                 s.append("  static constexpr uint32_t GLS_C[6][%d] = {%s};" % (n, ",\n    ".join(rows)))
+        # Membership of a G2 point of an MNT twist through psi = twist o Frobenius o untwist (psi^2 - t psi + q = 0, psi = [q mod r]
+        # = [t - 1] on the order-r subgroup): the endomorphism psi - [t - 1] has degree chi(t - 1) = q - t + 1 = r, so its kernel —
+        # r points, containing the subgroup — IS the subgroup:  P in G2  <=>  psi(P) == [t - 1]P, exact for any curve point, with
+        # |t - 1| ~ sqrt(r) (377 bits instead of 753).  psi(x, y) = (PSI_CX x^q, PSI_CY y^q), both constants in Fq.
+        s.append("  static constexpr int PSI_KIND = %d;" % (1 if psi else 0))
+        if psi:
+            pcx, pcy, pn, pneg, nwords = psi
+            s.append("  static constexpr uint32_t PSI_CX[%d] = {%s};" % (n, limbs(pcx * R % p, n)))
+            s.append("  static constexpr uint32_t PSI_CY[%d] = {%s};" % (n, limbs(pcy * R % p, n)))
+            s.append("  static constexpr uint32_t PSI_N[%d] = {%s};   // |t - 1|, packed words" % (nwords, limbs(pn, nwords, 32)))
+            s.append("  static constexpr bool PSI_NEG = %s;            // t - 1 < 0" % ("true" if pneg else "false"))
         s.append("  static constexpr int GLV_KIND = %d;   // 0 none, 1 half-size lambda (floor division), 2 lattice (Babai rounding)" % (1 if glv else (2 if glv2 else 0)))
         if glv2:
             # phi(x, y) = (BETA x, y) = LAMBDA (x, y); short basis (a1, b1), (a2, b2) of {(u, v): u + v LAMBDA = 0 mod r};
@@ -358,9 +369,13 @@ def main():
     out.append(coeffs("Bw6G2Cfg", fq_of("Bw6Fq"), 1, (0,), (4,), 0, glv2=(glv_beta_for(BW6_G2_XY, bw6_w, bw6_lam, BW6_Q), bw6_lam, BLS_Q),
                       cofactor=COFACTORS["bw6"][1]))
     out.append(coeffs("Mnt4G1Cfg", fq_of("Mnt4Fq"), 1, (2,), (MNT4_B1,), 0))
-    out.append(coeffs("Mnt4G2Cfg", fq_of("Mnt4Fq"), 2, (26, 0), (0, MNT4_B1 * 13 % MNT_A), 13, cofactor=COFACTORS["mnt4_753"][1]))
+    out.append(coeffs("Mnt4G2Cfg", fq_of("Mnt4Fq"), 2, (26, 0), (0, MNT4_B1 * 13 % MNT_A), 13, cofactor=COFACTORS["mnt4_753"][1],
+                      # quadratic twist by omega, omega^2 = u, u^2 = 13: psi_x = u^(1-q) = -1, psi_y = omega^(3(1-q)) = 13^((q-1)/4); t - 1 = q - r < 0
+                      psi=(MNT_A - 1, pow(13, (MNT_A - 1) // 4, MNT_A), MNT_B - MNT_A, True, 24)))
     out.append(coeffs("Mnt6G1Cfg", fq_of("Mnt6Fq"), 1, (11,), (MNT6_B1,), 0))
-    out.append(coeffs("Mnt6G2Cfg", fq_of("Mnt6Fq"), 3, (0, 0, 11), (MNT6_B1 * 11 % MNT_B, 0, 0), 11, cofactor=COFACTORS["mnt6_753"][1]))
+    out.append(coeffs("Mnt6G2Cfg", fq_of("Mnt6Fq"), 3, (0, 0, 11), (MNT6_B1 * 11 % MNT_B, 0, 0), 11, cofactor=COFACTORS["mnt6_753"][1],
+                      # omega^2 = u, u^3 = 11: psi_x = u^(1-q) = 11^(-(q-1)/3), psi_y = omega^(3(1-q)) = 11^(-(q-1)/2); t - 1 = q - r > 0
+                      psi=(pow(pow(11, (MNT_B - 1) // 3, MNT_B), -1, MNT_B), pow(pow(11, (MNT_B - 1) // 2, MNT_B), -1, MNT_B), MNT_B - MNT_A, False, 24)))
     # ---- pairing tail (host): Fq^k = Fq[w]/(w^k - NU), untwist sign, Frobenius constant, hard exponent
     def cyclo(k, q):
         return {4: q * q + 1, 6: q * q - q + 1, 12: q ** 4 - q * q + 1}[k]

@@ -1052,6 +1052,41 @@ endo_subgroup_kernel(const uint8_t *__restrict__ in, uint64_t n, int *__restrict
     if (bad) atomicOr(err, bad);
 }
 
+// ---- K3'' : membership of an MNT twist point through psi (gen_constants.py PSI_*): scratch[i] = [|t - 1|] P_i was left by
+// K1 (fixed scalar); accept iff psi(P_i) == +-scratch[i].  Exact for any curve point: the kernel of psi - [t - 1] has r points.
+template <class G>
+PTAU_HD int psi_check_thread(const uint8_t *in, int compressed_in, const typename G::J *scratch, uint64_t i) {
+    using F = typename G::F;
+    using B = typename F::Base;
+    using Cfg = typename G::J::CfgT;
+    static_assert(Cfg::PSI_KIND == 1 && F::DEG >= 2, "no psi membership test for this group");
+    typename G::A p;
+    int bad = read_point_any<G>(in, compressed_in, i, p);
+    if (bad) return bad;
+    if (p.inf) return 0;
+    const typename G::J R = scratch[i];
+    if (R.is_inf()) return ERRBIT_NOT_IN_SUBGROUP;
+    const B cx = B::load_const(Cfg::PSI_CX), cy = B::load_const(Cfg::PSI_CY);
+    F fx, fy;
+    if constexpr (F::DEG == 2) { fx = F::conj(p.x); fy = F::conj(p.y); }
+    else { fx = F::frobenius(p.x); fy = F::frobenius(p.y); }
+    const F ex = F::mul_base(fx, cx);
+    F ey = F::mul_base(fy, cy);
+    if (Cfg::PSI_NEG) ey = F::neg(ey);   // psi(P) = [t - 1]P = -[|t - 1|]P
+    const F zz = F::sqr(R.Z);
+    const bool ok = (R.X == F::mul(ex, zz)) && (R.Y == F::mul(ey, F::mul(zz, R.Z)));
+    return ok ? 0 : ERRBIT_NOT_IN_SUBGROUP;
+}
+template <class G>
+__global__ void __launch_bounds__(256, G::MIN_WAVES)
+psi_check_kernel(const uint8_t *__restrict__ in, int compressed_in, const typename G::J *__restrict__ scratch, uint64_t n,
+                 int *__restrict__ err) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int bad = psi_check_thread<G>(in, compressed_in, scratch, i);
+    if (bad) atomicOr(err, bad);
+}
+
 // Batched normalisation + serialisation.  Thread t owns elements t, t+T, t+2T, ... (< n).
 template <class G>
 PTAU_HD int normalize_thread(const typename G::J *scratch, typename G::F *pre, uint8_t *out, int compressed_out,
@@ -1167,6 +1202,9 @@ struct GroupOps {
     void (*endo_subgroup)(hipStream_t, const uint8_t *in, int cin, uint64_t n, int *err);
     // membership through K1's GLV loop with the fixed pair (a, b), [a]P + [b]phi(P) == O (SCALAR_SUBGROUP_ENDO): BW6-761
     bool subgroup_via_glv;
+    // membership through psi (MNT twists): K1 with the fixed scalar psi_scalar (fr_limbs32 words), then psi_check on its result
+    const uint32_t *psi_scalar;
+    void (*psi_check)(hipStream_t, const uint8_t *in, int cin, const void *scratch, uint64_t n, int *err);
     void (*decompress)(hipStream_t, const uint8_t *in, uint8_t *out, uint64_t n, int check_nonzero, int *err);
     const uint32_t *group_order;   // r, canonical 32-bit limbs (fr_limbs32)
     // O(1) host-side decompression for the pairing tail (a handful of public-key / head elements)
@@ -1305,6 +1343,12 @@ struct Launch {
             else hipLaunchKernelGGL((endo_subgroup_kernel<G, 0>), grid(n), dim3(256), 0, s, in, n, err);
         }
     }
+    static void psi_check(hipStream_t s, const uint8_t *in, int cin, const void *scratch, uint64_t n, int *err) {
+        if constexpr (G::J::CfgT::PSI_KIND == 1) {
+            if (!n) return;
+            hipLaunchKernelGGL(psi_check_kernel<G>, grid(n), dim3(256), 0, s, in, cin, (const typename G::J *)scratch, n, err);
+        }
+    }
     static void decompress(hipStream_t s, const uint8_t *in, uint8_t *out, uint64_t n, int check_nonzero, int *err) {
         if (!n) return;
         hipLaunchKernelGGL(decompress_kernel<G>, grid(n), dim3(256), 0, s, in, out, n, check_nonzero, err);
@@ -1338,6 +1382,14 @@ struct Launch {
         o.expect_infinity = expect_infinity;
         o.endo_subgroup = G::J::CfgT::ENDO_KIND != 0 ? endo_subgroup : nullptr;
         o.subgroup_via_glv = G::J::CfgT::GLV_KIND == 2;
+        if constexpr (G::J::CfgT::PSI_KIND == 1) {
+            static_assert(sizeof(G::J::CfgT::PSI_N) / 4 == Fr::N, "psi scalar must have the scalar field's word count");
+            o.psi_scalar = G::J::CfgT::PSI_N;
+            o.psi_check = psi_check;
+        } else {
+            o.psi_scalar = nullptr;
+            o.psi_check = nullptr;
+        }
         o.decompress = decompress;
         o.group_order = Fr::Params::MOD;
         o.decompress_host = decompress_host;

@@ -124,6 +124,16 @@ static int run(const std::string &op, uint64_t n, uint64_t start, int cin, int c
                 if (!b && !scratch[i].Z.is_zero()) b |= ERRBIT_NOT_IN_SUBGROUP;
                 out[i] = (uint8_t)b;
             }
+        } else if constexpr (G::J::CfgT::PSI_KIND == 1) {
+            // MNT twists: psi(P) == [t - 1]P — K1 with the fixed half-length scalar, then the psi comparison (capi.hip's order)
+            std::vector<typename G::J> scratch(n), wtab(8 * n);
+            const ScalarSource src{SCALAR_FIXED, G::J::CfgT::PSI_N, 0, 0, 0};
+            for (uint64_t i = 0; i < n; i++) {
+                int b = cin ? 0 : on_curve_thread<G>(in.data(), i);
+                b |= window_scalar_mul_thread<G>(in.data(), cin, scratch.data(), wtab.data(), n, i, src, 0, /*use_glv=*/0);
+                if (!b) b |= psi_check_thread<G>(in.data(), cin, scratch.data(), i);
+                out[i] = (uint8_t)b;
+            }
         } else {
             return 4;
         }

@@ -153,10 +153,11 @@ def test_bucket_msm_bodies_on_host(name, group, n, c, cref):
     assert r.returncode == 0 and r.stdout == exp_a + exp_b
 
 
-@pytest.mark.parametrize("name,group", [("bls12_377", 1), ("bls12_377", 2), ("bw6", 1), ("bw6", 2)])
+@pytest.mark.parametrize("name,group", [("bls12_377", 1), ("bls12_377", 2), ("bw6", 1), ("bw6", 2), ("mnt4_753", 2), ("mnt6_753", 2)])
 def test_endomorphism_subgroup_test_on_host(name, group):
     """Membership tests through an endomorphism — BLS12-377: phi on G1, psi on G2 (eprint 2021/1130); BW6-761:
-    [a]P + [b]phi(P) == O for the norm-r element a + b phi of Z[phi] — the kernel bodies, run on the CPU, accept exactly
+    [a]P + [b]phi(P) == O for the norm-r element a + b phi of Z[phi]; MNT4/MNT6-753 G2: psi(P) == [t - 1]P (psi - [t - 1] has
+    degree r) — the kernel bodies, run on the CPU, accept exactly
     the points the oracle's [r]P == O accepts: subgroup points, cofactor-only points, mixed points, small-order
     components, the point at infinity, for compressed and uncompressed encodings."""
     import random
