@@ -845,7 +845,27 @@ constexpr uint32_t MSM_RUN = 64;
 // as the group's own Affine (lane-pair groups pick their coefficient).
 template <class G>
 PTAU_HD typename G::A load_affine_std(const typename G::A *aff, uint64_t idx) {
-    if constexpr (G::LPP == 2) {
+    if constexpr (G::LANE_MODE == LANES_LIMB_SPLIT) {
+        // standard layout: x | y as DEG x N limbs each, then the flag word; this lane takes its H limbs of every coefficient
+        using L = typename G::Fq;
+        using F = typename G::F;
+        constexpr int D = F::DEG;
+        constexpr size_t WORDS = 2 * D * L::N + 1;
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(aff) + idx * WORDS;
+        const uint32_t *mine = w + (lane_parity() ? L::H : 0);
+        auto get = [&](int slot) {
+            L c;
+#pragma unroll
+            for (int j = 0; j < L::H; j++) c.l[j] = mine[slot * L::N + j];
+            return c;
+        };
+        typename G::A q;
+        if constexpr (D == 1) { q.x = get(0); q.y = get(1); }
+        else if constexpr (D == 2) { q.x = F::make(get(0), get(1)); q.y = F::make(get(2), get(3)); }
+        else { q.x = F::make(get(0), get(1), get(2)); q.y = F::make(get(3), get(4), get(5)); }
+        q.inf = *reinterpret_cast<const bool *>(w + 2 * D * L::N);
+        return q;
+    } else if constexpr (G::LPP == 2) {
         using Fq = typename G::Fq;
         constexpr size_t STRIDE = 4 * sizeof(Fq) + sizeof(uint32_t);   // sizeof(Affine<Fp2<Fq>>): 4 coefficients + flag word
         static_assert(sizeof(Affine<Fp2<Fq, 1>>) == STRIDE, "standard affine layout changed");
@@ -1289,7 +1309,8 @@ struct Launch {
     }
     static void msm_accumulate(hipStream_t s, const void *aff, const uint32_t *sorted, const uint32_t *offsets,
                                const uint32_t *run_offsets, void *partials, uint32_t shift, uint32_t total_buckets, uint64_t max_runs) {
-        if constexpr (twin_is<GL, LANES_FQ2_PAIR>()) {
+        if constexpr (!std::is_void_v<GL>) {
+            static_assert(sizeof(typename G::A) == (2 * G::F::DEG * G::Fq::N + 1) * 4 || G::Fq::LB != 29, "standard affine layout");
             if (lane_pair_enabled()) {   // two threads per run; affine input and Jacobian partials in G's layouts
                 hipLaunchKernelGGL(msm_accumulate_kernel<GL>, grid(max_runs * 2), dim3(256), 0, s, (const typename GL::A *)aff,
                                    sorted, offsets, run_offsets, (typename GL::J *)partials, shift, total_buckets);
