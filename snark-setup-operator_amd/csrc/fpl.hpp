@@ -558,11 +558,45 @@ struct FpL {
     }
     // off the hot path: the single-lane code, run redundantly by both lanes
     PTAU_HD static FpL inverse(const FpL &a) { return scatter(Full::inverse(a.gather())); }
-    PTAU_HD static bool sqrt_ex(const FpL &a, FpL &out, FpL *inv_out) {
-        Full o, io;
-        const bool ok = Full::sqrt_ex(a.gather(), o, inv_out ? &io : nullptr);
-        out = scatter(o);
-        if (inv_out) *inv_out = scatter(io);
+    __device__ __noinline__ static FpL pow_limbs(const FpL &a, const uint32_t *e, int top_bit) {
+        FpL r = one();
+        for (int i = top_bit; i >= 0; i--) {
+            r = sqr(r);
+            if ((e[i >> 5] >> (i & 31)) & 1u) r = mul(r, a);
+        }
+        return r;
+    }
+    // Square root on the pair: Fp::sqrt_ex's algorithm (one exponentiation + Pohlig-Hellman in the 2-Sylow subgroup) with the
+    // lane-split product / square; the table key is the element's lowest limb (even lane), broadcast to the pair.
+    __device__ __noinline__ static bool sqrt_ex(const FpL &a, FpL &out, FpL *inv_out) {
+        if (a.is_zero()) {
+            out = zero();
+            if (inv_out) *inv_out = zero();
+            return true;
+        }
+        const FpL w = pow_limbs(a, P::TS_TM1H, P::TS_TM1H_BITS - 1);
+        const FpL x = mul(a, w);
+        FpL b = mul(x, w);
+        FpL gd = one();
+        constexpr int E = P::TS_S - 1, W = P::SQRT_W;
+        bool ok = true;
+        for (int j = 0; j < P::SQRT_L; j++) {
+            const int wj = (E - W * j) < W ? (E - W * j) : W;
+            const int sh = E - W * j - wj;
+            FpL t = b;
+            for (int k = 0; k < sh; k++) t = sqr(t);
+            const uint32_t lo = lane_bcast_even(t.l[0]);
+            int K = -1;
+            for (int k = 0; k < (1 << W); k++) K = (P::SQRT_ZLOW[k] == lo) ? k : K;
+            if (K < 0) { ok = false; K = 0; }   // a^T outside <g^2>: non-residue (keep going: every lane of the pair runs the same calls)
+            const int d = K >> (W - wj);
+            const FpL f = load_const(P::SQRT_GNEG[(j << W) + d]);
+            gd = mul(gd, f);
+            b = mul(b, sqr(f));
+        }
+        out = mul(x, gd);
+        if (sqr(out) != a) ok = false;
+        if (inv_out) *inv_out = mul(out, sqr(mul(w, gd)));
         return ok;
     }
     PTAU_HD static bool sqrt(const FpL &a, FpL &out) { return sqrt_ex(a, out, nullptr); }

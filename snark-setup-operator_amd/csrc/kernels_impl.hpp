@@ -1185,7 +1185,7 @@ template <class G>
 __global__ void __launch_bounds__(256, G::MIN_WAVES)
 decompress_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, uint64_t n, int check_nonzero,
                   int *__restrict__ err) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G::LPP;
     if (i >= n) return;
     int bad = decompress_thread<G>(in, out, i, check_nonzero);
     if (bad) atomicOr(err, bad);
@@ -1372,6 +1372,12 @@ struct Launch {
     }
     static void decompress(hipStream_t s, const uint8_t *in, uint8_t *out, uint64_t n, int check_nonzero, int *err) {
         if (!n) return;
+        if constexpr (twin_is<GL, LANES_LIMB_SPLIT>()) {
+            if (lane_pair_enabled()) {   // square root on lane pairs (fpl.hpp); same bytes in, same bytes out
+                hipLaunchKernelGGL(decompress_kernel<GL>, grid(n * 2), dim3(256), 0, s, in, out, n, check_nonzero, err);
+                return;
+            }
+        }
         hipLaunchKernelGGL(decompress_kernel<G>, grid(n), dim3(256), 0, s, in, out, n, check_nonzero, err);
     }
     static int decompress_host(const uint8_t *in, uint8_t *out, uint64_t n, int check_nonzero) {
