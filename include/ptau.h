@@ -46,7 +46,9 @@ enum { PTAU_SUBGROUP_AUTO = 0, PTAU_SUBGROUP_DIRECT = 1, PTAU_SUBGROUP_BATCHED =
  *   AUTO / BATCH_INVERSION : the same, EXCEPT when prime-order-subgroup membership of every input element was established
  *                            in the same call (check_input >= PTAU_CHECK_ONLY_IN_GROUP): then the endomorphism-accelerated
  *                            multiplication runs (GLV on BLS12-377 G1 / BW6-761, GLS on BLS12-377 G2) — equal to [k]P on the
- *                            subgroup, ~1.4x faster;
+ *                            subgroup, ~1.4x faster.  Where that membership test is much cheaper than the saving (BLS12-377
+ *                            G2: 64 doublings against 188) Auto runs it by itself and takes the endomorphism path only when
+ *                            every element passed — the bytes are the plain path's either way;
  *   | PTAU_BATCH_EXP_INPUT_IN_SUBGROUP : the CALLER asserts membership (the challenge came out of a verifier that ran the
  *                            subgroup checks, which is what the coordinator hands a contributor): the endomorphism path runs
  *                            without a membership pass.  On an element outside the subgroup the result would differ from

@@ -93,12 +93,15 @@ bool use_window_kernel() {
 // established in the same call (check_input >= OnlyInGroup runs the subgroup kernels first) or the caller asserts it
 // (PTAU_BATCH_EXP_INPUT_IN_SUBGROUP: the challenge came out of a verifier that ran the subgroup checks); every other
 // combination takes the plain signed-window multiplication, exact on the whole curve.  Returns < 0 on a bad mode.
+// 2 = "probe": membership unknown, mode Auto — where the membership test is much cheaper than what the endomorphism saves
+// (BLS12-377 G2: psi(P) == [x]P is 64 doublings, GLS saves 188 of the 252) the vector is TESTED first and takes the
+// endomorphism path only if every element passed; otherwise the plain path runs.  Same bytes either way.
 int endo_allowed(int check_input, int batch_exp_mode) {
     const int mode = batch_exp_mode & ~PTAU_BATCH_EXP_INPUT_IN_SUBGROUP;
     if (mode != PTAU_BATCH_EXP_AUTO && mode != PTAU_BATCH_EXP_DIRECT && mode != PTAU_BATCH_EXP_BATCH_INVERSION) return -1;
     if (mode == PTAU_BATCH_EXP_DIRECT) return 0;
     if (batch_exp_mode & PTAU_BATCH_EXP_INPUT_IN_SUBGROUP) return 1;
-    return (check_input & 2) ? 1 : 0;
+    return (check_input & 2) ? 1 : 2;
 }
 
 struct DeviceCtx {
@@ -228,6 +231,13 @@ int run_apply_powers_dev(DeviceCtx *c, int curve, int group, const GroupOps *ops
     if (check_input & 2) {
         int rc = run_subgroup_check_dev(c, curve, group, ops, d_in, cin, n, err);
         if (rc) return rc;
+    }
+    if (use_endo == 2) {   // Auto, membership unknown: probe where the test is cheap next to the saving
+        use_endo = 0;
+        if (ops->membership_cheap && n) {
+            Err quiet{nullptr, 0};
+            if (run_subgroup_check_dev(c, curve, group, ops, d_in, cin, n, quiet) == PTAU_OK) use_endo = 1;
+        }
     }
     const bool windowed = use_window_kernel();
     const uint64_t launch_cap = windowed

@@ -1222,6 +1222,9 @@ struct GroupOps {
     void (*endo_subgroup)(hipStream_t, const uint8_t *in, int cin, uint64_t n, int *err);
     // membership through K1's GLV loop with the fixed pair (a, b), [a]P + [b]phi(P) == O (SCALAR_SUBGROUP_ENDO): BW6-761
     bool subgroup_via_glv;
+    // the membership test costs a small fraction of what the endomorphism multiplication saves over the plain one (BLS12-377
+    // G2: 64 doublings against 188): BatchExpMode::Auto probes the vector and takes the GLS path when every element passes
+    bool membership_cheap;
     // membership through psi (MNT twists): K1 with the fixed scalar psi_scalar (fr_limbs32 words), then psi_check on its result
     const uint32_t *psi_scalar;
     void (*psi_check)(hipStream_t, const uint8_t *in, int cin, const void *scratch, uint64_t n, int *err);
@@ -1409,6 +1412,7 @@ struct Launch {
         o.expect_infinity = expect_infinity;
         o.endo_subgroup = G::J::CfgT::ENDO_KIND != 0 ? endo_subgroup : nullptr;
         o.subgroup_via_glv = G::J::CfgT::GLV_KIND == 2;
+        o.membership_cheap = G::J::CfgT::ENDO_KIND == 2 && Fr::N == 8;
         if constexpr (G::J::CfgT::PSI_KIND == 1) {
             static_assert(sizeof(G::J::CfgT::PSI_N) / 4 == Fr::N, "psi scalar must have the scalar field's word count");
             o.psi_scalar = G::J::CfgT::PSI_N;
