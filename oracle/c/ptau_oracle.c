@@ -16,6 +16,7 @@
  */
 #include "ptau_oracle.h"
 
+#include <immintrin.h>
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
@@ -69,13 +70,43 @@ static int bn_bitlen(const u64 *a, int n) {
 }
 static int bn_bit(const u64 *a, int i) { return (int)((a[i >> 6] >> (i & 63)) & 1); }
 
+/* fixed-N bodies (carry chains the compiler keeps in registers); the generic loop serves other sizes */
+#define DEF_FP_ADDSUB(N)                                                                      \
+    static void fp_add_##N(const fpctx *c, u64 *z, const u64 *a, const u64 *b) {              \
+        u64 t[N], s[N];                                                                       \
+        unsigned char cy = 0, br = 0;                                                         \
+        _Pragma("GCC unroll 12") for (int i = 0; i < N; i++) cy = _addcarry_u64(cy, a[i], b[i], (unsigned long long *)&t[i]); \
+        _Pragma("GCC unroll 12") for (int i = 0; i < N; i++) br = _subborrow_u64(br, t[i], c->p[i], (unsigned long long *)&s[i]); \
+        const int reduced = cy | !br; /* a + b >= p */                                        \
+        _Pragma("GCC unroll 12") for (int i = 0; i < N; i++) z[i] = reduced ? s[i] : t[i];    \
+    }                                                                                         \
+    static void fp_sub_##N(const fpctx *c, u64 *z, const u64 *a, const u64 *b) {              \
+        u64 t[N];                                                                             \
+        unsigned char br = 0, cy = 0;                                                         \
+        _Pragma("GCC unroll 12") for (int i = 0; i < N; i++) br = _subborrow_u64(br, a[i], b[i], (unsigned long long *)&t[i]); \
+        const u64 mask = (u64)0 - br;                                                         \
+        _Pragma("GCC unroll 12") for (int i = 0; i < N; i++) cy = _addcarry_u64(cy, t[i], c->p[i] & mask, (unsigned long long *)&z[i]); \
+    }
+DEF_FP_ADDSUB(4)
+DEF_FP_ADDSUB(6)
+DEF_FP_ADDSUB(12)
 static void fp_add(const fpctx *c, u64 *z, const u64 *a, const u64 *b) {
+    switch (c->n) {
+    case 4: fp_add_4(c, z, a, b); return;
+    case 6: fp_add_6(c, z, a, b); return;
+    case 12: fp_add_12(c, z, a, b); return;
+    }
     u64 t[MAXL];
     u64 cy = bn_add(t, a, b, c->n);
     if (cy || bn_geq(t, c->p, c->n)) bn_sub(t, t, c->p, c->n);
     memcpy(z, t, 8 * c->n);
 }
 static void fp_sub(const fpctx *c, u64 *z, const u64 *a, const u64 *b) {
+    switch (c->n) {
+    case 4: fp_sub_4(c, z, a, b); return;
+    case 6: fp_sub_6(c, z, a, b); return;
+    case 12: fp_sub_12(c, z, a, b); return;
+    }
     u64 t[MAXL];
     if (bn_sub(t, a, b, c->n)) bn_add(t, t, c->p, c->n);
     memcpy(z, t, 8 * c->n);

@@ -1,3 +1,5 @@
+"""Host BLAKE2b throughput of the library's three compression functions (0 portable, 1 AVX2, 2 BMI2-compiled scalar) and of
+hashlib on this machine's CPU:  python3 tools/hash_bench.py   (the library picks by timing them on first use)."""
 import sys,time,hashlib,os
 sys.path.insert(0,'tests')
 from conftest import load_package
