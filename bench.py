@@ -238,7 +238,7 @@ def macs_per_update(curve, group, endo):
     product 2 N^2, square N^2 + N (N + 1) / 2 (lane-split fields: 2 N^2 - H (H - 1), H = N / 2); doubling 2M + 5S (a = 0) or
     3M + 6S (+ a small a * Z^4 chain); table of 8 multiples by 7 mixed additions (7M + 4S); signed 4-bit windows (15/16 of
     the digits are non-zero); window additions: mixed (7M + 4S) on the common-Z table of the j = 0 curves (+ 51 products to
-    rescale the table), full (11M + 5S) on the MNT curves.
+    rescale the table), full (11M + 5S) on the MNT curves.  BLS12-377 G1: the loop's products have 14 limbs (fpz.hpp).
     None for the extension-field groups (their base-product count depends on the lane mapping; not modelled)."""
     if group != 1 and curve != "bw6":
         return None
@@ -251,6 +251,16 @@ def macs_per_update(curve, group, endo):
     add = madd if a_zero else 11 * m + 5 * sq
     rescale = 51 * m if a_zero else 0
     bits = SCALAR_BITS[curve]
+    if curve == "bls12_377":
+        # the window loop runs in the carry-free twin field (fpz.hpp): 14 limbs of 28 bits; mixed addition 8M + 3S
+        # (Z3 = 2 Z1 H); 16 + 1 + 3 converting products (table entries, Zc, result), one more for beta
+        mz, sqz = 2 * 14 * 14, 14 * 14 + 14 * 15 // 2
+        dblz, maddz = 2 * mz + 5 * sqz, 8 * mz + 3 * sqz
+        table = 7 * madd + rescale + 20 * mz
+        if endo:
+            return (4 * 32 - 4) * dblz + 2 * 32 * 15 // 16 * maddz + 32 * 15 // 16 * mz + mz + table
+        windows = (bits + 3 + 3) // 4
+        return (4 * windows - 4) * dblz + windows * 15 // 16 * maddz + table
     if endo and a_zero:
         half = 128 if curve == "bls12_377" else 192
         windows = half // 4

@@ -1,0 +1,359 @@
+// Carry-free ("lazy") prime-field arithmetic for the inner loop of K1 on gfx950: 28-bit limbs, ONE LIMB MORE than the
+// modulus needs.
+//
+// Why (tools/ubench_valu.hip, profiles/r02_ubench_valu.txt): next to a v_mad_u64_u32 (5.2 cycles per wave64) a plain VALU
+// instruction is not free — 2.4-3.1 cycles for add / sub / and / right shift, 4.3-4.6 for every three-operand integer
+// form, 64-bit shift, carry through VCC, select — and a modular addition of the fully reduced 13 x 29-bit field is a ~100
+// instruction carry chain plus a conditional subtraction (~350 cycles, a fifth of a square).  A doubling has fourteen of
+// them: 26 % of its time.  Here R = 2^(28 N) >= 2^15 p, so
+//   * a sum is N limb-wise additions, a difference N limb-wise a_i + (K p)_i - b_i against a multiple of p whose limbs are
+//     pre-biased (no borrow can occur), a small multiple is a shift — no carry propagates, nothing is compared with p;
+//   * the product accepts such operands as they are (limbs up to 2^32, values up to 2^14 p) and returns limbs < 2^28 and a
+//     value below 2p WITHOUT a final conditional subtraction: (a b + m p) / R < a b / R + p;
+//   * carries are propagated (`norm`, 3 cheap instructions per limb) only where a limb bound would otherwise overflow.
+// The price is one more limb in the product: 378 multiply-accumulates instead of 325.
+//
+// Overflow safety is a COMPILE-TIME property: an element carries its bounds in its type, E<U, V> = "every limb below
+// U 2^28, value below V p"; each operation computes the bounds of its result and static_asserts what it needs
+// (product: U1 U2 <= 16 keeps a column sum below 2^64; V1 V2 <= 2^15 keeps the result below 2p).
+// Same Montgomery residue as Fp29 up to the constant factor R / R29: from29 / to29 convert by one product.
+// Used only between the window table and the result store of window_scalar_mul_kernel (kernels_impl.hpp, LAZY_LOOP); the
+// reference path it serves is batch_exp, /root/reference/src/bin/contribute.rs:811-823.
+#pragma once
+#include "fp29.hpp"
+
+namespace ptau {
+
+template <class P>
+struct FpZ {
+    static constexpr int N = P::N;
+    static constexpr int LB = P::LB;
+    static constexpr uint32_t MASK = (1u << LB) - 1u;
+    using F29 = Fp29<typename P::P29>;
+    static_assert(LB == 28 && P::MOD[0] == 1u && P::INV == MASK, "written for p = 1 mod 2^28");
+    static_assert(LB * N >= F29::Params::BITS + 15, "R must exceed 2^15 p");
+
+    template <int U, int V>
+    struct E {
+        static_assert(U >= 1 && U <= 15, "a limb would not fit 32 bits");
+        static_assert(V >= 1 && V <= (1 << 14), "the value would not stay below R");
+        static constexpr int LIMB_BOUND = U, VALUE_BOUND = V;
+        uint32_t l[N];
+        // widening only: a tighter bound is also a looser one
+        template <int U2, int V2>
+        PTAU_HD operator E<U2, V2>() const {
+            static_assert(U2 >= U && V2 >= V, "bounds can only be loosened");
+            E<U2, V2> r;
+#pragma unroll
+            for (int i = 0; i < N; i++) r.l[i] = l[i];
+            return r;
+        }
+    };
+    using Nrm = E<1, 2>;   // what a product returns
+
+    struct Limbs { uint32_t l[N]; };
+    // K p with every limb below the top raised by UB 2^28, each raise borrowed from the next limb up: the same integer,
+    // and limb i >= UB 2^28 - UB >= any limb below (UB - 1) 2^28; the top limb (K p >> 364) - UB still exceeds the top limb
+    // of any value below (K - 1) p.
+    static constexpr Limbs make_subc(int K, int UB) {
+        Limbs r{};
+        uint64_t c = 0;
+        for (int i = 0; i < N; i++) {
+            const uint64_t t = (uint64_t)K * P::MOD[i] + c;
+            if (i < N - 1) {
+                r.l[i] = (uint32_t)(t & MASK) + ((uint32_t)UB << LB) - (i ? (uint32_t)UB : 0u);
+                c = t >> LB;
+            } else {
+                r.l[i] = (uint32_t)t - (uint32_t)UB;
+            }
+        }
+        return r;
+    }
+    template <int K, int UB>
+    struct SubC {
+        static_assert(UB <= 15, "bias does not fit a limb");
+        static constexpr Limbs v = make_subc(K, UB);
+    };
+
+    template <int U1, int V1, int U2, int V2>
+    PTAU_HD static E<U1 + U2, V1 + V2> add(const E<U1, V1> &a, const E<U2, V2> &b) {
+        E<U1 + U2, V1 + V2> r;
+#pragma unroll
+        for (int i = 0; i < N; i++) r.l[i] = a.l[i] + b.l[i];
+        return r;
+    }
+    // a - b + (V2 + 1) p: non-negative limb by limb
+    template <int U1, int V1, int U2, int V2>
+    PTAU_HD static E<U1 + U2 + 2, V1 + V2 + 1> sub(const E<U1, V1> &a, const E<U2, V2> &b) {
+        E<U1 + U2 + 2, V1 + V2 + 1> r;
+#pragma unroll
+        for (int i = 0; i < N; i++) r.l[i] = a.l[i] + SubC<V2 + 1, U2 + 1>::v.l[i] - b.l[i];
+        return r;
+    }
+    template <int U, int V>
+    PTAU_HD static E<U + 2, V + 1> neg(const E<U, V> &a) {
+        E<U + 2, V + 1> r;
+#pragma unroll
+        for (int i = 0; i < N; i++) r.l[i] = SubC<V + 1, U + 1>::v.l[i] - a.l[i];
+        return r;
+    }
+    template <int K, int U, int V>
+    PTAU_HD static E<K * U, K * V> times(const E<U, V> &a) {
+        static_assert(K == 2 || K == 3 || K == 4 || K == 8, "small multiples used by the point formulas");
+        E<K * U, K * V> r;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            if constexpr (K == 2) r.l[i] = a.l[i] + a.l[i];
+            else if constexpr (K == 3) r.l[i] = a.l[i] + a.l[i] + a.l[i];
+            else if constexpr (K == 4) r.l[i] = a.l[i] << 2;
+            else r.l[i] = a.l[i] << 3;
+        }
+        return r;
+    }
+    // propagate carries: limbs < 2^28 again (the top limb keeps the value's high part: < V 2^13)
+    template <int U, int V>
+    PTAU_HD static E<1, V> norm(const E<U, V> &a) {
+        E<1, V> r;
+        uint32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < N - 1; i++) {
+            const uint32_t w = a.l[i] + c;   // < U 2^28 + 16 <= 2^32
+            r.l[i] = w & MASK;
+            c = w >> LB;
+        }
+        r.l[N - 1] = a.l[N - 1] + c;
+        return r;
+    }
+
+    // Montgomery product / square, product scanning, no final subtraction.  Column sums: at most N products of operand
+    // limbs (< U1 U2 2^56 each, U1 U2 <= 16) and N products m_j p_k (< 2^56): below 238 2^56 < 2^64.
+    template <bool SQR>
+    PTAU_HD static void ps_mul(const uint32_t (&a)[N], const uint32_t (&b)[N], uint32_t (&out)[N]) {
+        uint32_t m[N], d[N];
+        if constexpr (SQR) {
+#pragma unroll
+            for (int i = 0; i < N; i++) d[i] = a[i] + a[i];
+        }
+        uint64_t acc = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            if constexpr (SQR) {
+#pragma unroll
+                for (int j = 0; 2 * j < i; j++) mac64_vv(acc, d[j], a[i - j]);
+                if ((i & 1) == 0) mac64_vv(acc, a[i / 2], a[i / 2]);
+            } else {
+#pragma unroll
+                for (int j = 0; j <= i; j++) mac64_vv(acc, a[j], b[i - j]);
+            }
+#pragma unroll
+            for (int j = 0; j < i; j++) mac64_vs(acc, m[j], P::MOD[i - j]);
+            m[i] = (0u - (uint32_t)acc) & MASK;   // INV = -1
+            acc += m[i];                           // MOD[0] = 1
+            acc >>= LB;
+        }
+#pragma unroll
+        for (int i = N; i < 2 * N; i++) {
+            if constexpr (SQR) {
+#pragma unroll
+                for (int j = i - N + 1; 2 * j < i; j++) mac64_vv(acc, d[j], a[i - j]);
+                if ((i & 1) == 0 && i / 2 < N) mac64_vv(acc, a[i / 2], a[i / 2]);
+            } else {
+#pragma unroll
+                for (int j = i - N + 1; j < N; j++) mac64_vv(acc, a[j], b[i - j]);
+            }
+#pragma unroll
+            for (int j = i - N + 1; j < N; j++) mac64_vs(acc, m[j], P::MOD[i - j]);
+            out[i - N] = i == 2 * N - 1 ? (uint32_t)acc : ((uint32_t)acc & MASK);
+            acc >>= LB;
+        }
+    }
+    typedef uint32_t VecN __attribute__((ext_vector_type(N)));
+    __host__ __device__ __noinline__ static VecN mul_vec(VecN a, VecN b) {
+        uint32_t x[N], y[N], r[N];
+#pragma unroll
+        for (int i = 0; i < N; i++) { x[i] = a[i]; y[i] = b[i]; }
+        ps_mul<false>(x, y, r);
+        VecN o;
+#pragma unroll
+        for (int i = 0; i < N; i++) o[i] = r[i];
+        return o;
+    }
+    __host__ __device__ __noinline__ static VecN sqr_vec(VecN a) {
+        uint32_t x[N], r[N];
+#pragma unroll
+        for (int i = 0; i < N; i++) x[i] = a[i];
+        ps_mul<true>(x, x, r);
+        VecN o;
+#pragma unroll
+        for (int i = 0; i < N; i++) o[i] = r[i];
+        return o;
+    }
+    template <int U1, int V1, int U2, int V2>
+    PTAU_HD static Nrm mul(const E<U1, V1> &a, const E<U2, V2> &b) {
+        static_assert(U1 * U2 <= 16, "a column of the product would overflow 64 bits: normalise an operand first");
+        static_assert(V1 * V2 <= (1 << 15), "the product would not come back below 2p");
+        VecN x, y;
+#pragma unroll
+        for (int i = 0; i < N; i++) { x[i] = a.l[i]; y[i] = b.l[i]; }
+        const VecN o = mul_vec(x, y);
+        Nrm r;
+#pragma unroll
+        for (int i = 0; i < N; i++) r.l[i] = o[i];
+        return r;
+    }
+    template <int U, int V>
+    PTAU_HD static Nrm sqr(const E<U, V> &a) {
+        static_assert(U * U <= 16, "a column of the square would overflow 64 bits: normalise the operand first");
+        static_assert(V * V <= (1 << 15), "the square would not come back below 2p");
+        VecN x;
+#pragma unroll
+        for (int i = 0; i < N; i++) x[i] = a.l[i];
+        const VecN o = sqr_vec(x);
+        Nrm r;
+#pragma unroll
+        for (int i = 0; i < N; i++) r.l[i] = o[i];
+        return r;
+    }
+
+    PTAU_HD static Nrm zero() {
+        Nrm r;
+#pragma unroll
+        for (int i = 0; i < N; i++) r.l[i] = 0;
+        return r;
+    }
+    PTAU_HD static Nrm one() {
+        Nrm r;
+#pragma unroll
+        for (int i = 0; i < N; i++) r.l[i] = P::R1[i];
+        return r;
+    }
+    // value = 0 mod p?  A normalised value below V p is a multiple j p only if its lowest limb is j (p = 1 mod 2^28):
+    // one comparison settles all but a 2^-28-rare case, which is compared limb by limb with j p.
+    template <int V>
+    PTAU_HD static bool is_zero(const E<1, V> &a) {
+        const uint32_t j = a.l[0];
+        if (j >= (uint32_t)V) return false;
+        uint64_t c = 0;
+        uint32_t diff = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const uint64_t t = (uint64_t)j * P::MOD[i] + c;
+            diff |= a.l[i] ^ (i < N - 1 ? (uint32_t)(t & MASK) : (uint32_t)t);
+            c = t >> LB;
+        }
+        return diff == 0;
+    }
+    // literally all limbs zero (the table's marker for the point at infinity; from29(0) is exactly that)
+    template <int U, int V>
+    PTAU_HD static bool limbs_all_zero(const E<U, V> &a) {
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) o |= a.l[i];
+        return o == 0;
+    }
+
+    // Fp29 (fully reduced, R29 = 2^(29 N29)) <-> this representation
+    PTAU_HD static Nrm from29(const F29 &a) {
+        E<1, 1> t;
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            const int bit = LB * k, s = bit / 29, o = bit % 29;
+            uint32_t v = s < F29::N ? a.l[s] >> o : 0u;
+            if (o + LB > 29 && s + 1 < F29::N) v |= a.l[s + 1] << (29 - o);
+            t.l[k] = v & MASK;
+        }
+        E<1, 1> c;
+#pragma unroll
+        for (int i = 0; i < N; i++) c.l[i] = P::FROM29[i];
+        return mul(t, c);
+    }
+    template <int U, int V>
+    PTAU_HD static F29 to29(const E<U, V> &a) {
+        static_assert(U <= 16 && V <= (1 << 15), "operand of the converting product out of range");
+        E<1, 1> c;
+#pragma unroll
+        for (int i = 0; i < N; i++) c.l[i] = P::TO29[i];
+        const Nrm v = mul(a, c);
+        // below 2p: one conditional subtraction makes it canonical
+        uint32_t u[N];
+        int32_t cy = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const int32_t w = (int32_t)v.l[i] - (int32_t)P::MOD[i] + cy;
+            cy = w >> LB;
+            u[i] = i < N - 1 ? ((uint32_t)w & MASK) : (uint32_t)w;
+        }
+        uint32_t z[N + 1];
+#pragma unroll
+        for (int i = 0; i < N; i++) z[i] = cy < 0 ? v.l[i] : u[i];
+        z[N] = 0;
+        F29 r;
+#pragma unroll
+        for (int k = 0; k < F29::N; k++) {
+            const int bit = 29 * k, s = bit / LB, o = bit % LB;
+            uint32_t w = z[s] >> o;
+            if (s + 1 <= N) w |= z[s + 1] << (LB - o);
+            r.l[k] = w & F29::MASK;
+        }
+        return r;
+    }
+};
+
+// Jacobian arithmetic on y^2 = x^3 + b (a = 0) over FpZ: the window loop's doubling and mixed addition with every sum and
+// difference carry-free.  The bounds in the member types are closed under both operations (checked by the compiler through
+// E<>'s static_asserts): X below 31p, Y below 19p, Z below 2p, limbs normalised.
+template <class Z>
+struct LazyJac {
+    using Nrm = typename Z::Nrm;
+    using XT = typename Z::template E<1, 31>;
+    using YT = typename Z::template E<1, 19>;
+    using AY = typename Z::template E<3, 3>;   // an affine y, possibly negated on the fly
+    XT X;
+    YT Y;
+    Nrm Zc;   // = 0 mod p  <=>  point at infinity
+
+    PTAU_HD static LazyJac infinity() { return {Z::one(), Z::one(), Z::zero()}; }
+    PTAU_HD bool is_inf() const { return Z::is_zero(Zc); }
+
+    // dbl-2009-l
+    PTAU_HD static LazyJac dbl(const LazyJac &p) {
+        const auto A = Z::sqr(p.X);
+        const auto B = Z::sqr(p.Y);
+        const auto C = Z::sqr(B);
+        const auto T2 = Z::sqr(Z::add(p.X, B));
+        const auto D = Z::norm(Z::template times<2>(Z::sub(T2, Z::add(A, C))));   // 2((X+B)^2 - A - C)
+        const auto E3 = Z::template times<3>(A);
+        const auto F = Z::sqr(E3);
+        LazyJac r;
+        r.Zc = Z::mul(Z::template times<2>(p.Y), p.Zc);
+        r.X = Z::norm(Z::sub(F, Z::template times<2>(D)));
+        r.Y = Z::norm(Z::sub(Z::mul(E3, Z::sub(D, r.X)), Z::template times<8>(C)));
+        return r;
+    }
+
+    // madd-2007-bl with Z3 = 2 Z1 H; q = (x2, y2) affine and not the point at infinity
+    PTAU_HD static LazyJac add_mixed(const LazyJac &p, const Nrm &x2, const AY &y2) {
+        if (p.is_inf()) return {x2, Z::norm(y2), Z::one()};
+        const auto Z1Z1 = Z::sqr(p.Zc);
+        const auto U2 = Z::mul(x2, Z1Z1);
+        const auto S2 = Z::mul(Z::mul(y2, p.Zc), Z1Z1);
+        const auto H = Z::norm(Z::sub(U2, p.X));
+        const auto rh = Z::norm(Z::sub(S2, p.Y));
+        if (Z::is_zero(H)) {
+            if (Z::is_zero(rh)) return dbl(p);
+            return infinity();
+        }
+        const auto rr = Z::template times<2>(rh);
+        const auto HH = Z::sqr(H);
+        const auto I = Z::template times<4>(HH);
+        const auto J = Z::mul(H, I);
+        const auto Vv = Z::mul(p.X, I);
+        LazyJac r;
+        r.X = Z::norm(Z::sub(Z::sqr(rr), Z::add(J, Z::template times<2>(Vv))));
+        r.Y = Z::norm(Z::sub(Z::mul(rr, Z::sub(Vv, r.X)), Z::template times<2>(Z::mul(p.Y, J))));
+        r.Zc = Z::mul(Z::template times<2>(p.Zc), H);
+        return r;
+    }
+};
+
+}  // namespace ptau

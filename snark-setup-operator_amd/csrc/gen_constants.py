@@ -217,6 +217,25 @@ def main():
                               n_limbs=RADIX29_LIMBS.get(name))
             fields[name + "R29"] = (p, n, R, 29)
             out.append(txt)
+    # carry-free ("lazy") twin of a base field for the inner loop of K1 (fpz.hpp): 28-bit limbs, one limb more than the
+    # modulus needs, so that R = 2^(28 N) >= 2^15 p: sums and differences of a few elements stay valid operands of a product
+    # (no carry chain, no conditional subtraction) and a product brings any such operand back below 2p.
+    for name, p in (("BlsFq", BLS_Q),):
+        lb, n = 28, (p.bit_length() + 15 + 27) // 28
+        Rz, R29 = 1 << (lb * n), fields[name + "R29"][2]
+        assert Rz >= p << 15 and p % (1 << lb) == 1      # p = 1 mod 2^28: m_i = -acc mod 2^28, m_i p_0 is an addition
+        out.append("struct %sZ28 {" % name)
+        out.append("  static constexpr int LB = %d;" % lb)
+        out.append("  static constexpr int N = %d;" % n)
+        out.append("  static constexpr uint32_t INV = 0x%08xu;" % ((-pow(p, -1, 1 << lb)) % (1 << lb)))
+        out.append("  static constexpr uint32_t MOD[%d] = {%s};" % (n, limbs(p, n, lb)))
+        out.append("  static constexpr uint32_t R1[%d] = {%s};" % (n, limbs(Rz % p, n, lb)))
+        out.append("  static constexpr uint32_t FROM29[%d] = {%s};   // Rz^2 / R29 mod p: (x R29) -> (x Rz) by one product" % (n, limbs(Rz * Rz * pow(R29, -1, p) % p, n, lb)))
+        out.append("  static constexpr uint32_t TO29[%d] = {%s};     // R29 mod p: (x Rz) -> (x R29)" % (n, limbs(R29 % p, n, lb)))
+        out.append("  using P29 = %sR29;" % name)
+        out.append("};")
+        out.append("template <class P> struct LazyTwin { using type = void; };")
+        out.append("template <> struct LazyTwin<%sR29> { using type = %sZ28; };" % (name, name))
     fq_of = lambda base: base + "R29" if base in RADIX29 else base   # the struct a curve over `base` is generated for
     out.append("using Bw6Fr = BlsFq;")
     out.append("using Mnt4Fr = Mnt6Fq;")

@@ -21,6 +21,7 @@
 #include <type_traits>
 
 #include "ec.hpp"
+#include "fpz.hpp"
 
 #ifndef PTAU_G1_MIN_WAVES
 #define PTAU_G1_MIN_WAVES 2
@@ -87,6 +88,13 @@ struct GroupTypes {
 #define PTAU_AFFINE_TABLE 1
 #endif
     static constexpr bool AFFINE_TABLE = PTAU_AFFINE_TABLE && Cfg::A_IS_ZERO && F::DEG <= 2 && F::POINT_OPS_INLINE;
+    // K1's window loop in the carry-free twin of the base field (fpz.hpp): BLS12-377 G1.  The table is built as before and
+    // converted entry by entry; the accumulator is converted back before the result store.
+#ifndef PTAU_LAZY_LOOP
+#define PTAU_LAZY_LOOP 1
+#endif
+    using LazyP = typename LazyTwin<FqP>::type;
+    static constexpr bool LAZY_LOOP = PTAU_LAZY_LOOP && AFFINE_TABLE && LANE_MODE == LANES_ONE && F::DEG == 1 && !std::is_void<LazyP>::value;
     static constexpr int MIN_WAVES = LANE_MODE == LANES_LIMB_SPLIT ? PTAU_SPLIT_MIN_WAVES : LPP == 2 ? PTAU_LANE_MIN_WAVES : SMALL ? PTAU_G1_MIN_WAVES : (PTAU_MIN_WAVES_WIDE > 0 ? PTAU_MIN_WAVES_WIDE : 1);
 };
 
@@ -473,6 +481,23 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
     J cur = J::from_affine(p);
     wtab[slot] = cur;
     F zc = F::one();   // the table's common denominator (AFFINE_TABLE)
+    using LZ = FpZ<typename G::LazyP>;                                     // named only: instantiated under LAZY_LOOP
+    using AccT = std::conditional_t<G::LAZY_LOOP, LazyJac<LZ>, J>;       // the window loop's accumulator
+    // affine table entry e: (x, y) in the X and Y slots — or, for the carry-free loop, both converted, 2 x 14 limbs from the
+    // start of the entry's slot
+    auto put_entry = [&](int e, const F &x, const F &y) {
+        J *t = &wtab[(uint64_t)e * nslots + slot];
+        if constexpr (G::LAZY_LOOP) {
+            static_assert(sizeof(J) >= 2 * LZ::N * sizeof(uint32_t), "a converted entry must fit the Jacobian slot");
+            uint32_t *w = reinterpret_cast<uint32_t *>(t);
+            const auto lx = LZ::from29(x), ly = LZ::from29(y);
+#pragma unroll
+            for (int j = 0; j < LZ::N; j++) { w[j] = lx.l[j]; w[LZ::N + j] = ly.l[j]; }
+        } else {
+            t->X = x;
+            t->Y = y;
+        }
+    };
     if constexpr (G::AFFINE_TABLE) {
         // Jacobian multiples first, the running product of their Z's on the side; then, last to first, entry e is scaled by
         // c_e = Zc / Z_e = (product of the Z's before it) * (product of those after it): (X c^2, Y c^3) written to its X and
@@ -503,14 +528,12 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
                 q.X = F::mul(q.X, c2);
                 q.Y = F::mul(q.Y, F::mul(c2, c));
             }
-            wtab[(uint64_t)e * nslots + slot].X = q.X;
-            wtab[(uint64_t)e * nslots + slot].Y = q.Y;
+            put_entry(e, q.X, q.Y);
         }
         {   // entry 0 = P itself (Z = 1): c = Zc
             if constexpr (F::DEG == 2) zc = F::mul(zc, F::conj(zc));
             const F c2 = F::sqr(zc);
-            wtab[slot].X = F::mul(p.x, c2);
-            wtab[slot].Y = F::mul(p.y, F::mul(c2, zc));
+            put_entry(0, F::mul(p.x, c2), F::mul(p.y, F::mul(c2, zc)));
         }
     } else {
         for (int e = 1; e < WINDOW_ENTRIES; e++) {
@@ -519,8 +542,18 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
         }
     }
     // acc += (+-) table entry `mag` (with the GLV endomorphism applied when `endo`): a mixed addition on an affine table
-    auto add_entry = [&](J &acc, int mag, bool negate, bool endo, const F &beta) {
-        if constexpr (G::AFFINE_TABLE) {
+    auto add_entry = [&](AccT &acc, int mag, bool negate, bool endo, const auto &beta) {
+        if constexpr (G::LAZY_LOOP) {
+            const uint32_t *w = reinterpret_cast<const uint32_t *>(&wtab[(uint64_t)(mag - 1) * nslots + slot]);
+            typename LZ::Nrm x, y;
+#pragma unroll
+            for (int j = 0; j < LZ::N; j++) { x.l[j] = w[j]; y.l[j] = w[LZ::N + j]; }
+            if (LZ::limbs_all_zero(x) && LZ::limbs_all_zero(y)) return;   // the multiple is O
+            if (endo) x = LZ::mul(x, beta);
+            typename AccT::AY ys = y;
+            if (negate) ys = LZ::neg(y);
+            acc = AccT::add_mixed(acc, x, ys);
+        } else if constexpr (G::AFFINE_TABLE) {
             const J *t = &wtab[(uint64_t)(mag - 1) * nslots + slot];
             A q;
             q.x = t->X;
@@ -536,6 +569,22 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
             acc = J::add(acc, ent);
         }
     };
+    // leaving the loop: back from the isomorphic curve (Z Zc) and, for the carry-free accumulator, back to the reduced field
+    auto finish = [&](const AccT &acc) -> J {
+        if constexpr (G::LAZY_LOOP) {
+            const auto z = LZ::mul(acc.Zc, LZ::from29(zc));
+            return {LZ::to29(acc.X), LZ::to29(acc.Y), LZ::to29(z)};
+        } else {
+            J r = acc;
+            if constexpr (G::AFFINE_TABLE) r.Z = F::mul(r.Z, zc);
+            return r;
+        }
+    };
+    auto dbl_acc = [&](AccT &acc) { acc = AccT::dbl(acc); };
+    const auto no_beta = [&] {
+        if constexpr (G::LAZY_LOOP) return LZ::zero();
+        else return F::zero();
+    }();
     uint32_t k[NL];
     if (src.mode != SCALAR_SUBGROUP_ENDO) {
         thread_scalar<Fr>(src, i, k);
@@ -569,12 +618,16 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
 #pragma unroll
                 for (int j = 0; j < HL; j++) kk[h][j] = addc(kk[h][j], 0x88888888u, c2);   // halves < 2^(32 HL - 1): no carry out
             }
-            const F beta = F::load_const(Cfg::GLV_BETA);
-            J acc = J::infinity();
+            const F beta29 = F::load_const(Cfg::GLV_BETA);
+            const auto beta = [&] {
+                if constexpr (G::LAZY_LOOP) return LZ::from29(beta29);
+                else return beta29;
+            }();
+            AccT acc = AccT::infinity();
             for (int w = HL * 8 - 1; w >= 0; w--) {
                 if (!acc.is_inf()) {
 #pragma nounroll
-                    for (int d = 0; d < WINDOW_BITS; d++) acc = J::dbl(acc);
+                    for (int d = 0; d < WINDOW_BITS; d++) dbl_acc(acc);
                 }
 #pragma nounroll
                 for (int h = 0; h < 2; h++) {
@@ -588,8 +641,7 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
                     }
                 }
             }
-            if constexpr (G::AFFINE_TABLE) acc.Z = F::mul(acc.Z, zc);   // back from the isomorphic curve
-            store_jac<G>(scratch, i, acc);
+            store_jac<G>(scratch, i, finish(acc));
             return 0;
         }
     }
@@ -657,11 +709,11 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
     uint32_t c = 0;
 #pragma unroll
     for (int j = 0; j < NL; j++) k[j] = addc(k[j], 0x88888888u, c);
-    J acc = J::infinity();
+    AccT acc = AccT::infinity();
     for (int w = NW - 1; w >= 0; w--) {
         if (!acc.is_inf()) {
 #pragma nounroll
-            for (int d = 0; d < WINDOW_BITS; d++) acc = J::dbl(acc);
+            for (int d = 0; d < WINDOW_BITS; d++) dbl_acc(acc);
         }
         uint32_t limb = 0;
 #pragma unroll
@@ -669,11 +721,10 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
         int dgt = (int)((limb >> ((w & 7) * 4)) & 15u) - 8;
         if (dgt != 0) {
             int mag = dgt < 0 ? -dgt : dgt;
-            add_entry(acc, mag, dgt < 0, false, F::zero());
+            add_entry(acc, mag, dgt < 0, false, no_beta);
         }
     }
-    if constexpr (G::AFFINE_TABLE) acc.Z = F::mul(acc.Z, zc);   // back from the isomorphic curve
-    store_jac<G>(scratch, i, acc);
+    store_jac<G>(scratch, i, finish(acc));
     return 0;
 }
 

@@ -291,3 +291,58 @@ def test_rust_shim_declarations_match_the_header():
     from conftest import load_package
     pkg = load_package()
     assert set(c_funcs) == set(pkg._lib.DECLARED_SYMBOLS)
+
+
+def test_window_paths_on_small_order_and_cofactor_points_on_host(cref):
+    """K1's window loop of BLS12-377 G1 runs in the carry-free twin of the base field (fpz.hpp): bounds are compile-time, the
+    exceptional cases (a table multiple that is O, an addition that meets its own operand or its negative, a doubling of a
+    2-torsion point) go through residue tests on unreduced values.  Points of order 2, 3, 4, 6, 7, 8, 13 and 16, cofactor-only
+    and mixed points, the identity, against the oracle's double-and-add, for plain and edge scalars (exact path)."""
+    import random
+    from oracle.pyref import serde
+    from oracle.pyref.ec import Group
+    exe = os.path.join(ROOT, "tests", "native", "host_emul")
+    if not os.path.exists(exe):
+        pytest.skip("host_emul not built")
+    name = "bls12_377"
+    cv = CURVES[name]
+    G = Group(cv, 1)
+    rng = random.Random(77)
+    x = 0x8508c00000000001
+    h = (x - 1) ** 2 // 3
+    assert (h * cv.r - (cv.q + 1)) ** 2 < 4 * cv.q      # Hasse: h r is the curve order
+    F = G.F
+    def random_curve_point():
+        while True:
+            xx = (rng.randrange(cv.q),)
+            y = F.sqrt(F.add(F.mul(F.sqr(xx), xx), G.b))
+            if y is not None:
+                return (xx, y)
+    def point_of_order(ell, k, m):      # ell^k || h; a point of exact order ell^m
+        while True:
+            T = G.mul(G.mul(random_curve_point(), cv.r), h // ell ** k)     # order ell^j, j <= k
+            chain = []
+            while T is not None:
+                chain.append(T)
+                T = G.mul(T, ell)
+            if len(chain) >= m:
+                return chain[len(chain) - m]
+    small = {2: point_of_order(2, 92, 1), 4: point_of_order(2, 92, 2), 8: point_of_order(2, 92, 3), 16: point_of_order(2, 92, 4),
+             3: point_of_order(3, 1, 1), 7: point_of_order(7, 2, 1), 13: point_of_order(13, 2, 1)}
+    small[6] = G.add(small[2], small[3])
+    for o, T in small.items():
+        assert G.mul(T, o) is None and all(G.mul(T, o // f) is not None for f in (2, 3, 7, 13) if o % f == 0)
+    assert small[2][1] == (0,)
+    good = [G.mul(G.gen, rng.randrange(1, cv.r)) for _ in range(4)]
+    cof = G.mul(random_curve_point(), cv.r)
+    pts = [small[o] for o in sorted(small)] + [None, good[0], cof, G.add(good[1], small[3]), G.add(good[2], small[2]),
+                                               G.add(good[3], cof), random_curve_point()]
+    n = len(pts)
+    data = serde.write_batch(G, pts, False)
+    cid = CURVE_NAMES.index(name)
+    for start, tau, coeff in ((0, rng.randrange(cv.r), None), (3, 1, 0x8888888888888888888888888888888888888888), (0, 1, 1 << 200),
+                              (7, cv.r - 1, rng.randrange(cv.r)), (0, 2, 15), (1, 16, None), (5, 0, None), (0, rng.randrange(cv.r), 7)):
+        exp = cref.apply_powers(name, 1, data, n, start, tau, coeff, False, False, nthreads=8)
+        args = ["apply", str(cid), "1", str(n), str(start), "0", "0", "%x" % tau, "-" if coeff is None else "%x" % coeff]
+        r = subprocess.run([exe] + args, input=data, capture_output=True, env=dict(os.environ, PTAU_GLV="0"))
+        assert r.returncode == 0 and r.stdout == exp, (start, tau, coeff)
