@@ -21,6 +21,7 @@
 // reference path it serves is batch_exp, /root/reference/src/bin/contribute.rs:811-823.
 #pragma once
 #include "fp29.hpp"
+#include "fpl.hpp"   // lane_parity / lane_xchg / lane_bcast_*
 
 namespace ptau {
 
@@ -99,13 +100,14 @@ struct FpZ {
     }
     template <int K, int U, int V>
     PTAU_HD static E<K * U, K * V> times(const E<U, V> &a) {
-        static_assert(K == 2 || K == 3 || K == 4 || K == 8, "small multiples used by the point formulas");
+        static_assert(K == 2 || K == 3 || K == 4 || K == 5 || K == 8, "small multiples used by the point formulas");
         E<K * U, K * V> r;
 #pragma unroll
         for (int i = 0; i < N; i++) {
             if constexpr (K == 2) r.l[i] = a.l[i] + a.l[i];
             else if constexpr (K == 3) r.l[i] = a.l[i] + a.l[i] + a.l[i];
             else if constexpr (K == 4) r.l[i] = a.l[i] << 2;
+            else if constexpr (K == 5) r.l[i] = (a.l[i] << 2) + a.l[i];
             else r.l[i] = a.l[i] << 3;
         }
         return r;
@@ -122,6 +124,29 @@ struct FpZ {
             c = w >> LB;
         }
         r.l[N - 1] = a.l[N - 1] + c;
+        return r;
+    }
+
+    // Value reduction without a product: q = floor(top limb / (p's top limb + 1)) never exceeds value / p and misses it by
+    // less than 1 + V / 6884, so a - q p lies in [0, 3p) for V <= 256; limbs come out normalised (one borrow chain).
+    template <int V>
+    PTAU_HD static E<1, 3> vreduce(const E<1, V> &a) {
+        static_assert(V <= 256, "quotient estimate analysed for values below 256 p");
+        constexpr uint32_t D = P::MOD[N - 1] + 1u;
+        constexpr uint32_t MAGIC = (uint32_t)((1ull << 32) / D);           // floor: the estimate can only fall short
+        static_assert((uint64_t)256 * D < (1ull << 32), "top limb of the operand must fit the 32-bit estimate");
+        const uint32_t q = (uint32_t)(((uint64_t)a.l[N - 1] * MAGIC) >> 32);   // in {floor(top / D) - 1, floor(top / D)}
+        E<1, 3> r;
+        uint64_t c = 0;
+        int32_t b = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const uint64_t t = (uint64_t)q * P::MOD[i] + c;               // limb i of q p
+            c = t >> LB;
+            const int32_t v = (int32_t)a.l[i] - (int32_t)(i < N - 1 ? ((uint32_t)t & MASK) : (uint32_t)t) + b;
+            b = v >> LB;
+            r.l[i] = i < N - 1 ? ((uint32_t)v & MASK) : (uint32_t)v;
+        }
         return r;
     }
 
@@ -307,6 +332,7 @@ struct LazyJac {
     using Nrm = typename Z::Nrm;
     using XT = typename Z::template E<1, 31>;
     using YT = typename Z::template E<1, 19>;
+    using AX = Nrm;                            // affine x of a table entry
     using AY = typename Z::template E<3, 3>;   // an affine y, possibly negated on the fly
     XT X;
     YT Y;
@@ -352,6 +378,170 @@ struct LazyJac {
         r.X = Z::norm(Z::sub(Z::sqr(rr), Z::add(J, Z::template times<2>(Vv))));
         r.Y = Z::norm(Z::sub(Z::mul(rr, Z::sub(Vv, r.X)), Z::template times<2>(Z::mul(p.Y, J))));
         r.Zc = Z::mul(Z::template times<2>(p.Zc), H);
+        return r;
+    }
+};
+
+// Fq2 = Fq[u] / (u^2 + 5) over a LANE PAIR — a0 in the even lane, a1 in the odd lane, as Fp2L (ext.hpp) — with the
+// coefficients in FpZ.  Both lanes run the same instructions; what differs per lane is data: the partner's coefficient
+// arrives by one DPP move per limb (quad_perm exchange / broadcast), and the per-lane choice between the two combination
+// rules is a lane mask or a per-lane shift amount, not a branch.
+//   product:  even  a0 b0 - 5 a1 b1     odd  a1 b0 + a0 b1         (two base products per lane)
+//   square :  even  (a0 + a1)(a0 - 5 a1) + 4 a0 a1     odd  2 a0 a1   (ONE base product per lane)
+// Results are normalised, values below 13p / 10p; the base product's bounds (U1 U2 <= 16, V1 V2 <= 2^15) are checked at
+// compile time on the operands actually formed.
+template <class Z, int NR>
+struct Fp2Z {
+    static_assert(NR == -5, "combination rules written for the non-residue -5 (BLS12-377)");
+    static constexpr int N = Z::N;
+    template <int U, int V>
+    struct E {
+        typename Z::template E<U, V> c;
+        template <int U2, int V2>
+        PTAU_HD operator E<U2, V2>() const { return {c}; }
+    };
+    using M = E<1, 13>;   // a product
+    using S = E<1, 10>;   // a square
+    using R = E<1, 3>;    // after reduce()
+    using Nrm = typename Z::Nrm;
+
+    PTAU_HD static bool both(bool mine) {   // executed by both lanes of a pair, unconditionally
+        const uint32_t theirs = lane_xchg(mine ? 1u : 0u);
+        return mine && theirs != 0u;
+    }
+    template <class T>
+    PTAU_HD static T other(const T &v) {   // the partner lane's coefficient
+        T r;
+#pragma unroll
+        for (int i = 0; i < N; i++) r.l[i] = lane_xchg(v.l[i]);
+        return r;
+    }
+    template <int U1, int V1, int U2, int V2>
+    PTAU_HD static E<U1 + U2, V1 + V2> add(const E<U1, V1> &a, const E<U2, V2> &b) { return {Z::add(a.c, b.c)}; }
+    template <int U1, int V1, int U2, int V2>
+    PTAU_HD static E<U1 + U2 + 2, V1 + V2 + 1> sub(const E<U1, V1> &a, const E<U2, V2> &b) { return {Z::sub(a.c, b.c)}; }
+    template <int U, int V>
+    PTAU_HD static E<U + 2, V + 1> neg(const E<U, V> &a) { return {Z::neg(a.c)}; }
+    template <int K, int U, int V>
+    PTAU_HD static E<K * U, K * V> times(const E<U, V> &a) { return {Z::template times<K>(a.c)}; }
+    template <int U, int V>
+    PTAU_HD static E<1, V> norm(const E<U, V> &a) { return {Z::norm(a.c)}; }
+    template <int U, int V>
+    PTAU_HD static R reduce(const E<U, V> &a) { return {Z::vreduce(Z::norm(a.c))}; }
+    // (a0, -a1)
+    template <int U, int V>
+    PTAU_HD static E<U + 2, V + 1> conj(const E<U, V> &a) {
+        const bool odd = lane_parity() != 0;
+        const auto n = Z::neg(a.c);
+        E<U + 2, V + 1> r;
+#pragma unroll
+        for (int i = 0; i < N; i++) r.c.l[i] = odd ? n.l[i] : a.c.l[i];
+        return r;
+    }
+    // by an element of Fq (the same value in both lanes)
+    template <int U, int V, class KT>
+    PTAU_HD static E<1, 2> mul_base(const E<U, V> &a, const KT &k) { return {Z::mul(a.c, k)}; }
+
+    template <int U1, int V1, int U2, int V2>
+    PTAU_HD static M mul(const E<U1, V1> &a, const E<U2, V2> &b) {
+        const bool odd = lane_parity() != 0;
+        typename Z::template E<U2, V2> b0, b1;
+#pragma unroll
+        for (int i = 0; i < N; i++) { b0.l[i] = lane_bcast_even(b.c.l[i]); b1.l[i] = lane_bcast_odd(b.c.l[i]); }
+        const Nrm t1 = Z::mul(a.c, b0);                        // even a0 b0   odd a1 b0
+        const Nrm t2 = Z::mul(other(a.c), b1);                 // even a1 b1   odd a0 b1
+        const auto m5 = Z::sub(t1, Z::template times<5>(t2));  // <8, 13>
+        typename Z::template E<8, 13> r;
+#pragma unroll
+        for (int i = 0; i < N; i++) r.l[i] = odd ? t1.l[i] + t2.l[i] : m5.l[i];
+        return {Z::norm(r)};
+    }
+    template <int V>
+    PTAU_HD static S sqr(const E<1, V> &a) {
+        const uint32_t em = lane_parity() ? 0u : 0xffffffffu;   // all ones in the even lane
+        const auto ot = other(a.c);
+        const auto m5 = Z::sub(a.c, Z::template times<5>(ot));  // even: a0 - 5 a1 (+ a multiple of p)   <8, 6V + 1>
+        typename Z::template E<2, 2 * V> l;
+        typename Z::template E<8, 6 * V + 1> r;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            l.l[i] = ot.l[i] + (a.c.l[i] & em);                 // even a0 + a1     odd a0
+            r.l[i] = (m5.l[i] & em) | (a.c.l[i] & ~em);         // even a0 - 5 a1   odd a1
+        }
+        const Nrm t = Z::mul(l, r);                             // even (a0 + a1)(a0 - 5 a1)   odd a0 a1
+        // even: t + 4 v with v = the odd lane's t; odd: t + t.  One broadcast and one shift-add with a per-lane shift amount.
+        const uint32_t sh = em & 2u;
+        typename Z::template E<5, 10> o;
+#pragma unroll
+        for (int i = 0; i < N; i++) o.l[i] = t.l[i] + (lane_bcast_odd(t.l[i]) << sh);
+        return {Z::norm(o)};
+    }
+    PTAU_HD static E<1, 2> zero() { return {Z::zero()}; }
+    PTAU_HD static E<1, 2> one() {
+        const bool odd = lane_parity() != 0;
+        const Nrm o = Z::one();
+        E<1, 2> r;
+#pragma unroll
+        for (int i = 0; i < N; i++) r.c.l[i] = odd ? 0u : o.l[i];
+        return r;
+    }
+    template <int V>
+    PTAU_HD static bool is_zero(const E<1, V> &a) { return both(Z::is_zero(a.c)); }
+    template <int U, int V>
+    PTAU_HD static bool limbs_all_zero(const E<U, V> &a) { return both(Z::limbs_all_zero(a.c)); }
+};
+
+// Jacobian arithmetic on y^2 = x^3 + b' over Fp2Z (a = 0).  Coordinates between operations: X and Y reduced below 3p, Z a
+// product (below 13p), all normalised; every intermediate bound is in the types.
+template <class K>
+struct LazyJac2 {
+    using XT = typename K::R;
+    using YT = typename K::R;
+    using ZT = typename K::M;
+    using AX = typename K::template E<1, 2>;   // affine x of a table entry (possibly after psi^j)
+    using AY = typename K::template E<3, 3>;   // affine y, possibly negated on the fly
+    XT X;
+    YT Y;
+    ZT Zc;
+
+    PTAU_HD static LazyJac2 infinity() { return {K::one(), K::one(), K::zero()}; }
+    PTAU_HD bool is_inf() const { return K::is_zero(Zc); }
+
+    PTAU_HD static LazyJac2 dbl(const LazyJac2 &p) {
+        const auto A = K::sqr(p.X);
+        const auto B = K::sqr(p.Y);
+        const auto C = K::sqr(B);
+        const auto T2 = K::sqr(K::norm(K::add(p.X, B)));
+        const auto D = K::norm(K::template times<2>(K::sub(T2, K::add(A, C))));   // <1, 62>
+        const auto E3 = K::norm(K::template times<3>(A));                          // <1, 30>
+        const auto F = K::sqr(E3);
+        LazyJac2 r;
+        r.Zc = K::mul(K::template times<2>(p.Y), p.Zc);
+        r.X = K::reduce(K::sub(F, K::template times<2>(D)));
+        r.Y = K::reduce(K::sub(K::mul(E3, K::sub(D, r.X)), K::template times<8>(C)));
+        return r;
+    }
+    // q = (x2, y2) affine, not the point at infinity
+    PTAU_HD static LazyJac2 add_mixed(const LazyJac2 &p, const AX &x2, const AY &y2) {
+        if (p.is_inf()) return {x2, K::norm(y2), K::one()};
+        const auto Z1Z1 = K::sqr(p.Zc);
+        const auto U2 = K::mul(x2, Z1Z1);
+        const auto S2 = K::mul(K::mul(y2, p.Zc), Z1Z1);
+        const auto H = K::norm(K::sub(U2, p.X));     // <1, 17>
+        const auto rh = K::norm(K::sub(S2, p.Y));    // <1, 17>
+        if (K::is_zero(H)) {
+            if (K::is_zero(rh)) return dbl(p);
+            return infinity();
+        }
+        const auto R2 = K::template times<4>(K::sqr(rh));   // (2 rh)^2
+        const auto HH = K::sqr(H);
+        const auto I = K::template times<4>(HH);
+        const auto J = K::mul(H, I);
+        const auto Vv = K::mul(p.X, I);
+        LazyJac2 r;
+        r.X = K::reduce(K::sub(R2, K::add(J, K::template times<2>(Vv))));
+        r.Y = K::reduce(K::sub(K::mul(K::template times<2>(rh), K::sub(Vv, r.X)), K::template times<2>(K::mul(p.Y, J))));
+        r.Zc = K::mul(K::template times<2>(p.Zc), H);
         return r;
     }
 };

@@ -23,6 +23,7 @@ RADIX29 = {"BlsFq", "Mnt4Fq", "Mnt6Fq", "Bw6Fq"}
 # BW6-761 (round 2): 28 limbs of 29 bits — one more than ceil(761 / 29) — so that the element splits evenly over a lane pair
 # (fpl.hpp); its single-lane kernels (verify path) use the same representation so both kinds of kernel exchange values limb for limb.
 RADIX29_LIMBS = {"Bw6Fq": 28}
+LAZY28 = {"BlsFq"}      # base fields that also get a carry-free 28-bit twin (fpz.hpp)
 
 
 # The MNT twists' G2 generators are NOT here: ark-mnt4-753 / ark-mnt6-753's constants are not recoverable offline, so the
@@ -220,7 +221,7 @@ def main():
     # carry-free ("lazy") twin of a base field for the inner loop of K1 (fpz.hpp): 28-bit limbs, one limb more than the
     # modulus needs, so that R = 2^(28 N) >= 2^15 p: sums and differences of a few elements stay valid operands of a product
     # (no carry chain, no conditional subtraction) and a product brings any such operand back below 2p.
-    for name, p in (("BlsFq", BLS_Q),):
+    for name, p in ((nm, fields[nm][0]) for nm in sorted(LAZY28)):
         lb, n = 28, (p.bit_length() + 15 + 27) // 28
         Rz, R29 = 1 << (lb * n), fields[name + "R29"][2]
         assert Rz >= p << 15 and p % (1 << lb) == 1      # p = 1 mod 2^28: m_i = -acc mod 2^28, m_i p_0 is an addition
@@ -262,6 +263,15 @@ def main():
                     rows.append("{%s}" % limbs(pow(endo[2], j, p) * R % p, n))
                     rows.append("{%s}" % limbs(pow(endo[3], j, p) * R % p, n))
                 s.append("  static constexpr uint32_t GLS_C[6][%d] = {%s};" % (n, ",\n    ".join(rows)))
+                if fname.endswith("R29") and fname[:-3] in LAZY28:
+                    # the same six constants for the carry-free twin field (fpz.hpp): 28-bit limbs, R = 2^(28 NZ)
+                    nz = (p.bit_length() + 15 + 27) // 28
+                    Rz = 1 << (28 * nz)
+                    rows = []
+                    for j in (1, 2, 3):
+                        rows.append("{%s}" % limbs(pow(endo[2], j, p) * Rz % p, nz, 28))
+                        rows.append("{%s}" % limbs(pow(endo[3], j, p) * Rz % p, nz, 28))
+                    s.append("  static constexpr uint32_t GLS_CZ[6][%d] = {%s};" % (nz, ",\n    ".join(rows)))
         # Membership of a G2 point of an MNT twist through psi = twist o Frobenius o untwist (psi^2 - t psi + q = 0, psi = [q mod r]
         # = [t - 1] on the order-r subgroup): the endomorphism psi - [t - 1] has degree chi(t - 1) = q - t + 1 = r, so its kernel —
         # r points, containing the subgroup — IS the subgroup:  P in G2  <=>  psi(P) == [t - 1]P, exact for any curve point, with

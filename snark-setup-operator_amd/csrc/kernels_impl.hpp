@@ -88,13 +88,14 @@ struct GroupTypes {
 #define PTAU_AFFINE_TABLE 1
 #endif
     static constexpr bool AFFINE_TABLE = PTAU_AFFINE_TABLE && Cfg::A_IS_ZERO && F::DEG <= 2 && F::POINT_OPS_INLINE;
-    // K1's window loop in the carry-free twin of the base field (fpz.hpp): BLS12-377 G1.  The table is built as before and
-    // converted entry by entry; the accumulator is converted back before the result store.
+    // K1's window loop in the carry-free twin of the base field (fpz.hpp): BLS12-377 G1, and G2 with Fq2 over a lane pair.
+    // The table is built as before and converted entry by entry; the accumulator is converted back before the result store.
 #ifndef PTAU_LAZY_LOOP
 #define PTAU_LAZY_LOOP 1
 #endif
     using LazyP = typename LazyTwin<FqP>::type;
-    static constexpr bool LAZY_LOOP = PTAU_LAZY_LOOP && AFFINE_TABLE && LANE_MODE == LANES_ONE && F::DEG == 1 && !std::is_void<LazyP>::value;
+    static constexpr bool LAZY_LOOP = PTAU_LAZY_LOOP && AFFINE_TABLE && !std::is_void<LazyP>::value &&
+                                      ((LANE_MODE == LANES_ONE && F::DEG == 1) || (LANE_MODE == LANES_FQ2_PAIR && F::DEG == 2));
     static constexpr int MIN_WAVES = LANE_MODE == LANES_LIMB_SPLIT ? PTAU_SPLIT_MIN_WAVES : LPP == 2 ? PTAU_LANE_MIN_WAVES : SMALL ? PTAU_G1_MIN_WAVES : (PTAU_MIN_WAVES_WIDE > 0 ? PTAU_MIN_WAVES_WIDE : 1);
 };
 
@@ -458,6 +459,45 @@ PTAU_HD void store_jac(typename G::J *scratch, uint64_t i, const typename G::J &
     }
 }
 
+// The carry-free field of a group (named only under G::LAZY_LOOP): the loop's accumulator type, conversion from / to the
+// group's reduced field, and this lane's limbs of an element.
+template <class G>
+struct LazyOf {
+    using F = typename G::F;
+    using LZ = FpZ<typename G::LazyP>;
+    static constexpr bool PAIR = F::DEG == 2;
+    using K = std::conditional_t<PAIR, Fp2Z<LZ, G::J::CfgT::NR>, LZ>;
+    using Acc = std::conditional_t<PAIR, LazyJac2<K>, LazyJac<LZ>>;
+    using AX = typename Acc::AX;
+    using AY = typename Acc::AY;
+    static constexpr int N = LZ::N;
+    PTAU_HD static AX to_lazy(const F &x) {
+        if constexpr (PAIR) return {LZ::from29(x.c)};
+        else return LZ::from29(x);
+    }
+    template <class T>
+    PTAU_HD static F from_lazy(const T &v) {
+        if constexpr (PAIR) return {LZ::to29(v.c)};
+        else return LZ::to29(v);
+    }
+    template <class T>
+    PTAU_HD static uint32_t *limbs(T &v) {
+        if constexpr (PAIR) return v.c.l;
+        else return v.l;
+    }
+    PTAU_HD static AX load(const uint32_t *w) {
+        AX r;
+#pragma unroll
+        for (int j = 0; j < N; j++) limbs(r)[j] = w[j];
+        return r;
+    }
+};
+
+template <class G, bool LAZY>
+struct LoopAcc { using type = typename G::J; };
+template <class G>
+struct LoopAcc<G, true> { using type = typename LazyOf<G>::Acc; };
+
 template <class G>
 PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typename G::J *scratch,
                                      typename G::J *wtab, uint64_t n, uint64_t i, const ScalarSource &src,
@@ -481,18 +521,18 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
     J cur = J::from_affine(p);
     wtab[slot] = cur;
     F zc = F::one();   // the table's common denominator (AFFINE_TABLE)
-    using LZ = FpZ<typename G::LazyP>;                                     // named only: instantiated under LAZY_LOOP
-    using AccT = std::conditional_t<G::LAZY_LOOP, LazyJac<LZ>, J>;       // the window loop's accumulator
+    using L = LazyOf<G>;                                   // named only: instantiated under LAZY_LOOP
+    using AccT = typename LoopAcc<G, G::LAZY_LOOP>::type;   // the window loop's accumulator
     // affine table entry e: (x, y) in the X and Y slots — or, for the carry-free loop, both converted, 2 x 14 limbs from the
     // start of the entry's slot
     auto put_entry = [&](int e, const F &x, const F &y) {
         J *t = &wtab[(uint64_t)e * nslots + slot];
         if constexpr (G::LAZY_LOOP) {
-            static_assert(sizeof(J) >= 2 * LZ::N * sizeof(uint32_t), "a converted entry must fit the Jacobian slot");
+            static_assert(sizeof(J) >= 2 * L::N * sizeof(uint32_t), "a converted entry must fit the Jacobian slot");
             uint32_t *w = reinterpret_cast<uint32_t *>(t);
-            const auto lx = LZ::from29(x), ly = LZ::from29(y);
+            auto lx = L::to_lazy(x), ly = L::to_lazy(y);
 #pragma unroll
-            for (int j = 0; j < LZ::N; j++) { w[j] = lx.l[j]; w[LZ::N + j] = ly.l[j]; }
+            for (int j = 0; j < L::N; j++) { w[j] = L::limbs(lx)[j]; w[L::N + j] = L::limbs(ly)[j]; }
         } else {
             t->X = x;
             t->Y = y;
@@ -544,14 +584,16 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
     // acc += (+-) table entry `mag` (with the GLV endomorphism applied when `endo`): a mixed addition on an affine table
     auto add_entry = [&](AccT &acc, int mag, bool negate, bool endo, const auto &beta) {
         if constexpr (G::LAZY_LOOP) {
+            using K = typename L::K;
             const uint32_t *w = reinterpret_cast<const uint32_t *>(&wtab[(uint64_t)(mag - 1) * nslots + slot]);
-            typename LZ::Nrm x, y;
-#pragma unroll
-            for (int j = 0; j < LZ::N; j++) { x.l[j] = w[j]; y.l[j] = w[LZ::N + j]; }
-            if (LZ::limbs_all_zero(x) && LZ::limbs_all_zero(y)) return;   // the multiple is O
-            if (endo) x = LZ::mul(x, beta);
-            typename AccT::AY ys = y;
-            if (negate) ys = LZ::neg(y);
+            auto x = L::load(w);
+            const auto y = L::load(w + L::N);
+            if (K::limbs_all_zero(x) && K::limbs_all_zero(y)) return;   // the multiple is O
+            if constexpr (!L::PAIR) {
+                if (endo) x = K::mul(x, beta);
+            }
+            typename L::AY ys = y;
+            if (negate) ys = K::neg(y);
             acc = AccT::add_mixed(acc, x, ys);
         } else if constexpr (G::AFFINE_TABLE) {
             const J *t = &wtab[(uint64_t)(mag - 1) * nslots + slot];
@@ -572,8 +614,8 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
     // leaving the loop: back from the isomorphic curve (Z Zc) and, for the carry-free accumulator, back to the reduced field
     auto finish = [&](const AccT &acc) -> J {
         if constexpr (G::LAZY_LOOP) {
-            const auto z = LZ::mul(acc.Zc, LZ::from29(zc));
-            return {LZ::to29(acc.X), LZ::to29(acc.Y), LZ::to29(z)};
+            const auto z = L::K::mul(acc.Zc, L::to_lazy(zc));
+            return {L::from_lazy(acc.X), L::from_lazy(acc.Y), L::from_lazy(z)};
         } else {
             J r = acc;
             if constexpr (G::AFFINE_TABLE) r.Z = F::mul(r.Z, zc);
@@ -582,7 +624,7 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
     };
     auto dbl_acc = [&](AccT &acc) { acc = AccT::dbl(acc); };
     const auto no_beta = [&] {
-        if constexpr (G::LAZY_LOOP) return LZ::zero();
+        if constexpr (G::LAZY_LOOP) return L::K::zero();
         else return F::zero();
     }();
     uint32_t k[NL];
@@ -620,7 +662,7 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
             }
             const F beta29 = F::load_const(Cfg::GLV_BETA);
             const auto beta = [&] {
-                if constexpr (G::LAZY_LOOP) return LZ::from29(beta29);
+                if constexpr (G::LAZY_LOOP) return L::to_lazy(beta29);
                 else return beta29;
             }();
             AccT acc = AccT::infinity();
@@ -659,11 +701,11 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
                 lo[h] = dj[h] + 0x8888888888888888ull;
                 hi[h] = 8u + (lo[h] < dj[h] ? 1u : 0u);
             }
-            J acc = J::infinity();
+            AccT acc = AccT::infinity();
             for (int w = 16; w >= 0; w--) {
                 if (!acc.is_inf()) {
 #pragma nounroll
-                    for (int d = 0; d < WINDOW_BITS; d++) acc = J::dbl(acc);
+                    for (int d = 0; d < WINDOW_BITS; d++) dbl_acc(acc);
                 }
 #pragma nounroll
                 for (int h = 0; h < 4; h++) {
@@ -675,6 +717,28 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
                     const int dgt = (int)nib - 8;
                     if (dgt != 0) {
                         const int mag = dgt < 0 ? -dgt : dgt;
+                        if constexpr (G::LAZY_LOOP) {
+                            using K = typename L::K;
+                            const uint32_t *tw = reinterpret_cast<const uint32_t *>(&wtab[(uint64_t)(mag - 1) * nslots + slot]);
+                            auto x = L::load(tw), y = L::load(tw + L::N);
+                            if (!(K::limbs_all_zero(x) && K::limbs_all_zero(y))) {
+                                if (h) {   // psi^h of the entry: conjugate for odd h, then one Fq constant per coordinate
+                                    typename L::LZ::template E<1, 1> cx, cy;
+#pragma unroll
+                                    for (int j = 0; j < L::N; j++) { cx.l[j] = Cfg::GLS_CZ[2 * (h - 1)][j]; cy.l[j] = Cfg::GLS_CZ[2 * (h - 1) + 1][j]; }
+                                    typename K::template E<3, 3> xc = x, yc = y;
+                                    if (h & 1) {
+                                        xc = K::conj(x);
+                                        yc = K::conj(y);
+                                    }
+                                    x = K::mul_base(xc, cx);
+                                    y = K::mul_base(yc, cy);
+                                }
+                                typename L::AY ys = y;
+                                if (dgt < 0) ys = K::neg(y);
+                                acc = AccT::add_mixed(acc, x, ys);
+                            }
+                        } else {
                         J ent = wtab[(uint64_t)(mag - 1) * nslots + slot];   // affine table: Z slot unused (real common Z)
                         if (h) {
                             B cx, cy;
@@ -698,11 +762,11 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
                         } else {
                             acc = J::add(acc, ent);
                         }
+                        }
                     }
                 }
             }
-            if constexpr (G::AFFINE_TABLE) acc.Z = F::mul(acc.Z, zc);   // back from the isomorphic curve
-            store_jac<G>(scratch, i, acc);
+            store_jac<G>(scratch, i, finish(acc));
             return 0;
         }
     }

@@ -28,7 +28,7 @@
     X(15, "v_add3_u32", "v_add3_u32 %1, %1, %2, %3", 1)                                                          \
     X(16, "v_add_lshl_u32", "v_add_lshl_u32 %1, %1, %2, 3", 1)                                                   \
     X(17, "v_alignbit_b32", "v_alignbit_b32 %1, %1, %2, 29", 1)                                                  \
-    X(18, "v_cndmask_b32 (vcc)", "v_cndmask_b32 %1, %1, %2, vcc", 1)                                             \
+    X(18, "v_cndmask_b32 (sgpr mask)", "v_cndmask_b32_e64 %1, %1, %2, %5", 1)                                    \
     X(19, "v_mov_b32", "v_mov_b32 %1, %2", 1)                                                                    \
     X(20, "v_mov_b32 dpp quad_perm", "v_mov_b32_dpp %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf", 1)   \
     X(21, "v_add_co_u32", "v_add_co_u32 %1, vcc, %2, %1", 1)                                                     \
@@ -55,12 +55,13 @@ __global__ void __launch_bounds__(256) k(uint32_t *out, uint32_t seed) {
     uint64_t acc[CH];
     uint32_t hi[CH];
     const uint64_t a64 = ((uint64_t)b << 32) | a;
+    const uint64_t smask = __builtin_amdgcn_readfirstlane(seed) * 0x9e3779b97f4a7c15ull;   // a wave-uniform lane mask
     for (int i = 0; i < CH; i++) { acc[i] = i + a; hi[i] = i ^ b; }
     for (int it = 0; it < ITER; it++) {
 #pragma unroll
         for (int i = 0; i < CH; i++) {
 #define X(ID, NAME, ASM, N) \
-            if (MODE == ID) asm volatile(ASM : "+v"(acc[i]), "+v"(hi[i]) : "v"(a), "v"(b), "v"(a64) : "vcc", "a0");
+            if (MODE == ID) asm volatile(ASM : "+v"(acc[i]), "+v"(hi[i]) : "v"(a), "v"(b), "v"(a64), "s"(smask) : "vcc", "a0");
             OPS(X)
 #undef X
         }
