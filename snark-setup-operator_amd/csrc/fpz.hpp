@@ -332,8 +332,8 @@ struct LazyJac {
     using Nrm = typename Z::Nrm;
     using XT = typename Z::template E<1, 31>;
     using YT = typename Z::template E<1, 19>;
-    using AX = Nrm;                            // affine x of a table entry
-    using AY = typename Z::template E<3, 3>;   // an affine y, possibly negated on the fly
+    using AX = typename Z::template E<1, 3>;   // affine x of the point added (a table entry, or a reduced coordinate)
+    using AY = typename Z::template E<3, 4>;   // its y, possibly negated on the fly
     XT X;
     YT Y;
     Nrm Zc;   // = 0 mod p  <=>  point at infinity
@@ -358,7 +358,7 @@ struct LazyJac {
     }
 
     // madd-2007-bl with Z3 = 2 Z1 H; q = (x2, y2) affine and not the point at infinity
-    PTAU_HD static LazyJac add_mixed(const LazyJac &p, const Nrm &x2, const AY &y2) {
+    PTAU_HD static LazyJac add_mixed(const LazyJac &p, const AX &x2, const AY &y2) {
         if (p.is_inf()) return {x2, Z::norm(y2), Z::one()};
         const auto Z1Z1 = Z::sqr(p.Zc);
         const auto U2 = Z::mul(x2, Z1Z1);

@@ -255,6 +255,10 @@ def main():
             s.append("  static constexpr uint64_t ENDO_X = 0x%xull;" % endo[1])
             s.append("  static constexpr uint32_t ENDO_C0[%d] = {%s};" % (n, limbs(endo[2] * R % p, n)))
             s.append("  static constexpr uint32_t ENDO_C1[%d] = {%s};" % (n, limbs(endo[3] * R % p, n)))
+            if fname.endswith("R29") and fname[:-3] in LAZY28:   # the same constants for the carry-free twin field (fpz.hpp)
+                nz = (p.bit_length() + 15 + 27) // 28
+                s.append("  static constexpr uint32_t ENDO_C0Z[%d] = {%s};" % (nz, limbs(endo[2] * (1 << (28 * nz)) % p, nz, 28)))
+                s.append("  static constexpr uint32_t ENDO_C1Z[%d] = {%s};" % (nz, limbs(endo[3] * (1 << (28 * nz)) % p, nz, 28)))
             if endo[0] == 2:
                 # psi^j (X, Y, Z) = (C0^j conj^j(X), C1^j conj^j(Y), conj^j(Z)), j = 1..3: rows (C0^j, C1^j) for the
                 # 4-dimensional decomposition k = k0 + k1 X + k2 X^2 + k3 X^3 (psi acts as [X] on G2, r < X^4)

@@ -1152,6 +1152,49 @@ PTAU_HD int endo_subgroup_thread(const uint8_t *in, int compressed_in, uint64_t 
     if (p.inf) return 0;
     if (!compressed_in && !(F::sqr(p.y) == curve_rhs<F, Cfg>(p.x))) return ERRBIT_NOT_ON_CURVE;
     constexpr uint64_t X = Cfg::ENDO_X;
+    if constexpr (G::LAZY_LOOP) {
+        // the same test in the carry-free field (fpz.hpp).  G1's second multiplication by X starts from a Jacobian point
+        // (Xb, Yb, Zb): that is the affine point (Xb, Yb) of the isomorphic curve y^2 = x^3 + b Zb^6, neither the doubling nor
+        // the mixed addition involves b, so the chain runs there with mixed additions and Z maps back as Z Zb.
+        using L = LazyOf<G>;
+        using K = typename L::K;
+        using Acc = typename L::Acc;
+        const auto px = L::to_lazy(p.x), py = L::to_lazy(p.y);
+        const typename L::AY pya = py;
+        Acc t = {px, py, K::one()};
+        for (int b = 62; b >= 0; b--) {   // bit 63 of X is set
+            t = Acc::dbl(t);
+            if ((X >> b) & 1ull) t = Acc::add_mixed(t, px, pya);
+        }
+        if (t.is_inf()) return ERRBIT_NOT_IN_SUBGROUP;
+        typename L::LZ::template E<1, 1> c0, c1;
+#pragma unroll
+        for (int j = 0; j < L::N; j++) { c0.l[j] = Cfg::ENDO_C0Z[j]; c1.l[j] = Cfg::ENDO_C1Z[j]; }
+        if constexpr (Cfg::ENDO_KIND == 1) {
+            const auto zb = t.Zc;
+            const auto bx = K::vreduce(t.X), by = K::vreduce(t.Y);   // below 3p, as add_mixed takes them
+            const typename L::AX bxa = bx;
+            const typename L::AY bya = by;
+            Acc u = {bx, by, K::one()};
+            for (int b = 62; b >= 0; b--) {
+                u = Acc::dbl(u);
+                if ((X >> b) & 1ull) u = Acc::add_mixed(u, bxa, bya);
+            }
+            if (u.is_inf()) return ERRBIT_NOT_IN_SUBGROUP;
+            const auto zf = K::mul(u.Zc, zb);
+            const auto zz = K::sqr(zf);
+            const auto ex = K::mul(px, c0);
+            const bool okx = K::is_zero(K::norm(K::sub(u.X, K::mul(ex, zz))));
+            const bool oky = K::is_zero(K::norm(K::add(u.Y, K::mul(py, K::mul(zz, zf)))));   // Y == -y Z^3
+            return okx && oky ? 0 : ERRBIT_NOT_IN_SUBGROUP;
+        } else {
+            const auto ex = K::mul_base(K::conj(px), c0), ey = K::mul_base(K::conj(py), c1);
+            const auto zz = K::sqr(t.Zc);
+            const bool okx = K::is_zero(K::norm(K::sub(t.X, K::mul(ex, zz))));
+            const bool oky = K::is_zero(K::norm(K::sub(t.Y, K::mul(ey, K::mul(zz, t.Zc)))));
+            return okx && oky ? 0 : ERRBIT_NOT_IN_SUBGROUP;
+        }
+    }
     J t = J::from_affine(p);
     for (int b = 62; b >= 0; b--) {   // bit 63 of X is set
         t = J::dbl(t);
