@@ -6,6 +6,7 @@
 //   op = apply | decompress
 //        field : base-field arithmetic of the group's Fq class.  stdin = n pairs (a, b) of canonical BYTES-long elements;
 //               stdout per pair: a+b | a-b | a*b | a^2 | -a | 1/a (0 for a = 0) | sqrt flag byte + root (0 when none) | sign byte
+//        fieldz: the same input; arithmetic of the carry-free twin field (fpz.hpp), see the op
 //        subgroup : stdin = n points; stdout = n bytes of error bits (0 = in the prime-order subgroup)
 //        msm  : stdin = n points (uncompressed) then n x Fr::N u32 scalar limbs; <start> = window bits c (0 = the
 //               library's own plan), <cout> = 1 adds the shifted sum (needs n + 1 points); stdout = 1 or 2 points
@@ -63,6 +64,49 @@ static int run(const std::string &op, uint64_t n, uint64_t start, int cin, int c
         }
         fwrite(out.data(), 1, out.size(), stdout);
         return 0;
+    }
+    if (op == "fieldz") {
+        // the carry-free twin of the group's base field (fpz.hpp): every result converted back and written canonically.
+        // per pair (a, b): a+b | a-b | a*b | a^2 | -a | 5a - 8b (unnormalised operands into a product by 1) |
+        //                  vreduce(31 a + 19 b ... as the point formulas stack them) | flags byte: bit0 is_zero(a - a), bit1
+        //                  is_zero(a - b), bit2 is_zero(of 33 p built from limbs), bit3 is_zero(a) on the normalised value
+        if constexpr (!std::is_void<typename G::LazyP>::value && G::F::DEG == 1) {
+            using Fq = typename G::Fq;
+            using Z = FpZ<typename G::LazyP>;
+            const int B = Fq::BYTES;
+            in.resize(n * 2 * B);
+            if (fread(in.data() + n * isz, 1, in.size() - n * isz, stdin) != in.size() - n * isz && in.size() > n * isz) return 2;
+            out.assign(n * (7 * B + 1), 0);
+            for (uint64_t i = 0; i < n; i++) {
+                Fq a29, b29;
+                uint8_t fl = 0;
+                if (!Fq::read_bytes(in.data() + (2 * i) * B, false, &fl, a29) || !Fq::read_bytes(in.data() + (2 * i + 1) * B, false, &fl, b29)) return 5;
+                const auto a = Z::from29(a29), b = Z::from29(b29);
+                uint8_t *o = out.data() + i * (7 * B + 1);
+                Z::to29(Z::add(a, b)).write_bytes(o, 0);
+                Z::to29(Z::sub(a, b)).write_bytes(o + B, 0);
+                Z::to29(Z::mul(a, b)).write_bytes(o + 2 * B, 0);
+                Z::to29(Z::sqr(a)).write_bytes(o + 3 * B, 0);
+                Z::to29(Z::neg(a)).write_bytes(o + 4 * B, 0);
+                Z::to29(Z::sub(Z::template times<5>(a), Z::template times<8>(b))).write_bytes(o + 5 * B, 0);
+                // a stack of sums and differences as deep as the point formulas make them, then the quotient-estimate reduction
+                const auto s1 = Z::norm(Z::add(Z::template times<8>(a), Z::template times<4>(b)));          // < 24 p
+                const auto big = Z::norm(Z::sub(Z::norm(Z::template times<8>(s1)), Z::template times<2>(a)));  // < 197 p
+                Z::to29(Z::vreduce(big)).write_bytes(o + 6 * B, 0);
+                uint8_t f = 0;
+                f |= Z::is_zero(Z::norm(Z::sub(a, a))) ? 1 : 0;
+                f |= Z::is_zero(Z::norm(Z::sub(a, b))) ? 2 : 0;
+                typename Z::template E<1, 34> kp;
+                for (int j = 0; j < Z::N; j++) kp.l[j] = Z::template SubC<33, 0>::v.l[j];   // 33 p, plain limbs
+                f |= Z::is_zero(kp) ? 4 : 0;
+                f |= Z::is_zero(a) ? 8 : 0;
+                o[7 * B] = f;
+            }
+            fwrite(out.data(), 1, out.size(), stdout);
+            return 0;
+        } else {
+            return 6;
+        }
     }
     if (op == "msm") {
         // the per-thread bodies of the bucket MSM (K4), serial on the CPU, same order of launches as capi.hip

@@ -346,3 +346,32 @@ def test_window_paths_on_small_order_and_cofactor_points_on_host(cref):
         args = ["apply", str(cid), "1", str(n), str(start), "0", "0", "%x" % tau, "-" if coeff is None else "%x" % coeff]
         r = subprocess.run([exe] + args, input=data, capture_output=True, env=dict(os.environ, PTAU_GLV="0"))
         assert r.returncode == 0 and r.stdout == exp, (start, tau, coeff)
+
+
+def test_carry_free_field_arithmetic_on_host():
+    """fpz.hpp (the 14 x 28-bit carry-free twin of the BLS12-377 base field, K1's inner loop): conversion from / to the
+    reduced field, limb-wise sums and differences, products of unnormalised operands, the quotient-estimate reduction and the
+    residue tests, against Python integers on edge values (0, 1, p-1, limb-boundary patterns) and random ones."""
+    import random
+    exe = os.path.join(ROOT, "tests", "native", "host_emul")
+    if not os.path.exists(exe):
+        pytest.skip("host_emul not built")
+    cv = CURVES["bls12_377"]
+    p, B = cv.q, cv.fq_bytes
+    rng = random.Random(11)
+    edge = [0, 1, 2, p - 1, p - 2, (p - 1) // 2, (p + 1) // 2, (1 << 28) - 1, 1 << 28, (1 << 29) - 1, (1 << 56) - 1, (1 << 364) - 1,
+            1 << 364, (1 << 376) - 1, 1 << 376, int("fffffff" * 13, 16) % p, int("8000000" * 13, 16) % p, p - (1 << 28), p - (1 << 364)]
+    vals = [(a, b) for a in edge for b in (0, 1, p - 1, a, (p - a) % p, edge[(edge.index(a) * 5 + 2) % len(edge)])]
+    vals += [(rng.randrange(p), rng.randrange(p)) for _ in range(300)]
+    data = b"".join(a.to_bytes(B, "little") + b.to_bytes(B, "little") for a, b in vals)
+    r = subprocess.run([exe, "fieldz", "0", "1", str(len(vals)), "0", "0", "0", "0", "-"], input=data, capture_output=True)
+    assert r.returncode == 0, r.returncode
+    rec = 7 * B + 1
+    assert len(r.stdout) == rec * len(vals)
+    for i, (a, b) in enumerate(vals):
+        o = r.stdout[i * rec:(i + 1) * rec]
+        g = lambda k: int.from_bytes(o[k * B:(k + 1) * B], "little")
+        assert g(0) == (a + b) % p and g(1) == (a - b) % p and g(2) == a * b % p and g(3) == a * a % p and g(4) == (-a) % p
+        assert g(5) == (5 * a - 8 * b) % p
+        assert g(6) == (62 * a + 32 * b) % p
+        assert o[7 * B] == (1 | (2 if a == b else 0) | 4 | (8 if a == 0 else 0)), (a, b, o[7 * B])
