@@ -273,12 +273,7 @@ struct Fp3 {
         return {a.c0, F::mul(a.c1, c1), F::mul(a.c2, c2)};
     }
     __host__ __device__ __noinline__ static Fp3 pow_limbs(const Fp3 &a, const uint32_t *e, int top_bit) {
-        Fp3 r = one();
-        for (int i = top_bit; i >= 0; i--) {
-            r = sqr(r);
-            if ((e[i >> 5] >> (i & 31)) & 1u) r = mul(r, a);
-        }
-        return r;
+        return pow_sliding(a, e, top_bit);
     }
     // sqrt through the norm: b = (a^((q+1)/2))^q = a^((q^2+q)/2), so b^2 * a = a^(1+q+q^2) = N(a) in Fq
     // and sqrt(a) = sqrt_Fq(N(a)) / b.   One 753-bit Fq3 exponentiation + one base-field sqrt.

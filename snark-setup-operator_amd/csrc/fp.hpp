@@ -71,6 +71,42 @@ PTAU_HD void acc_shift(Acc96 &a) {
     a.hi = 0;
 }
 
+// a^e for a PUBLIC exponent (wave-uniform control flow): sliding 4-bit windows over the odd powers a, a^3, ..., a^15, kept
+// in a local array (private memory; the index is the same in every lane) — about top_bit / 5 + 8 products instead of one
+// per set bit (the square roots' exponents are dense: 377- and 753-bit exponents cost ~85 / ~160 products instead of
+// ~165 / ~376).
+template <class F>
+PTAU_HD F pow_sliding(const F &a, const uint32_t *e, int top_bit) {
+    F tab[8];
+    tab[0] = a;
+    const F a2 = F::sqr(a);
+    for (int i = 1; i < 8; i++) tab[i] = F::mul(tab[i - 1], a2);
+    auto bit = [&](int i) -> uint32_t { return (e[i >> 5] >> (i & 31)) & 1u; };
+    F r = F::one();
+    bool started = false;
+    int i = top_bit;
+    while (i >= 0) {
+        if (!bit(i)) {
+            if (started) r = F::sqr(r);
+            i--;
+            continue;
+        }
+        int j = i >= 3 ? i - 3 : 0;
+        while (!bit(j)) j++;   // the window ends on its lowest set bit
+        uint32_t val = 0;
+        for (int k = i; k >= j; k--) val = (val << 1) | bit(k);
+        if (started) {
+            for (int k = i; k >= j; k--) r = F::sqr(r);
+            r = F::mul(r, tab[val >> 1]);
+        } else {
+            r = tab[val >> 1];
+            started = true;
+        }
+        i = j - 1;
+    }
+    return r;
+}
+
 template <class P>
 struct Fp {
     static constexpr int N = P::N;
@@ -332,12 +368,7 @@ struct Fp {
 
     // a^e for a public exponent given as N 32-bit limbs (MSB-first square-and-multiply)
     __host__ __device__ __noinline__ static Fp pow_limbs(const Fp &a, const uint32_t *e, int top_bit) {
-        Fp r = one();
-        for (int i = top_bit; i >= 0; i--) {
-            r = sqr(r);
-            if ((e[i >> 5] >> (i & 31)) & 1u) r = mul(r, a);
-        }
-        return r;
+        return pow_sliding(a, e, top_bit);
     }
     PTAU_HD static Fp inverse_fermat(const Fp &a) { return pow_limbs(a, P::PM2, P::BITS - 1); }
     // Montgomery inverse by the binary extended Euclid (Kaliski): phase 1 yields a^-1 2^k mod p for the k <= 2 BITS

@@ -365,12 +365,7 @@ struct Fp29 {
     }
 
     __host__ __device__ __noinline__ static Fp29 pow_limbs(const Fp29 &a, const uint32_t *e, int top_bit) {
-        Fp29 r = one();
-        for (int i = top_bit; i >= 0; i--) {
-            r = sqr(r);
-            if ((e[i >> 5] >> (i & 31)) & 1u) r = mul(r, a);
-        }
-        return r;
+        return pow_sliding(a, e, top_bit);
     }
     // Inversion runs on the packed twin (Kaliski's binary almost-inverse, fp.hpp): for the raw integer v it returns
     // v^-1 2^(64 N32); with v = a R that is (a^-1 R) 2^(64 N32 - 58 N), and the Montgomery product with the constant

@@ -559,12 +559,7 @@ struct FpL {
     // off the hot path: the single-lane code, run redundantly by both lanes
     PTAU_HD static FpL inverse(const FpL &a) { return scatter(Full::inverse(a.gather())); }
     __device__ __noinline__ static FpL pow_limbs(const FpL &a, const uint32_t *e, int top_bit) {
-        FpL r = one();
-        for (int i = top_bit; i >= 0; i--) {
-            r = sqr(r);
-            if ((e[i >> 5] >> (i & 31)) & 1u) r = mul(r, a);
-        }
-        return r;
+        return pow_sliding(a, e, top_bit);
     }
     // Square root on the pair: Fp::sqrt_ex's algorithm (one exponentiation + Pohlig-Hellman in the 2-Sylow subgroup) with the
     // lane-split product / square; the table key is the element's lowest limb (even lane), broadcast to the pair.

@@ -480,16 +480,21 @@ struct LazyOf {
         if constexpr (PAIR) return {LZ::to29(v.c)};
         else return LZ::to29(v);
     }
-    template <class T>
-    PTAU_HD static uint32_t *limbs(T &v) {
-        if constexpr (PAIR) return v.c.l;
-        else return v.l;
-    }
     PTAU_HD static AX load(const uint32_t *w) {
         AX r;
 #pragma unroll
-        for (int j = 0; j < N; j++) limbs(r)[j] = w[j];
+        for (int j = 0; j < N; j++) {
+            if constexpr (PAIR) r.c.l[j] = w[j];
+            else r.l[j] = w[j];
+        }
         return r;
+    }
+    PTAU_HD static void store(uint32_t *w, const AX &v) {
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            if constexpr (PAIR) w[j] = v.c.l[j];
+            else w[j] = v.l[j];
+        }
     }
 };
 
@@ -530,9 +535,8 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
         if constexpr (G::LAZY_LOOP) {
             static_assert(sizeof(J) >= 2 * L::N * sizeof(uint32_t), "a converted entry must fit the Jacobian slot");
             uint32_t *w = reinterpret_cast<uint32_t *>(t);
-            auto lx = L::to_lazy(x), ly = L::to_lazy(y);
-#pragma unroll
-            for (int j = 0; j < L::N; j++) { w[j] = L::limbs(lx)[j]; w[L::N + j] = L::limbs(ly)[j]; }
+            L::store(w, L::to_lazy(x));
+            L::store(w + L::N, L::to_lazy(y));
         } else {
             t->X = x;
             t->Y = y;
