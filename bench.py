@@ -261,6 +261,15 @@ def macs_per_update(curve, group, endo):
             return (4 * 32 - 4) * dblz + 2 * 32 * 15 // 16 * maddz + 32 * 15 // 16 * mz + mz + table
         windows = (bits + 3 + 3) // 4
         return (4 * windows - 4) * dblz + windows * 15 // 16 * maddz + table
+    if curve == "bw6":
+        # the window loop runs in the carry-free lane-split field (fplz.hpp): the same 28 limbs; mixed addition 8M + 3S;
+        # 16 + 1 + 3 converting products, one more for beta
+        maddz = 8 * m + 3 * sq
+        table = 7 * madd + rescale + 20 * m
+        if endo:
+            return (4 * 48 - 4) * dbl + 2 * 48 * 15 // 16 * maddz + 48 * 15 // 16 * m + m + table
+        windows = (bits + 3 + 3) // 4
+        return (4 * windows - 4) * dbl + windows * 15 // 16 * maddz + table
     if endo and a_zero:
         half = 128 if curve == "bls12_377" else 192
         windows = half // 4

@@ -1,0 +1,380 @@
+// The carry-free field (fpz.hpp) for a WIDE modulus split over a lane pair, as FpL (fpl.hpp): the low half of the limbs in
+// the even lane, the high half in the odd lane — BW6-761: 28 limbs of 28 bits, R = 2^784 >= 2^23 p, the same limb count as
+// the reduced 28 x 29-bit form, so the products cost the same multiply-accumulates and lose their normalising tail, and
+// every sum / difference of the point formulas becomes H limb-wise instructions per lane (they were ~230-instruction
+// chains across the pair: carry folds through DPP, conditional subtraction).
+//   * E<U, V>: this lane's H limbs, "every limb below U 2^28 (+ a carry's worth), value below V p" — bounds checked at
+//     compile time exactly as in FpZ (a slot of the distributed accumulator row sums 2H products: U1 U2 <= 16).
+//   * the product is FpL's row-distributed operand scanning; its tail only propagates carries (the even lane's carry-out
+//     enters the odd lane's two lowest limbs, no ripple: limb 1 may exceed 2^28 by < 2^9, inside the column bound's slack).
+//   * residue tests: the value's lowest limb decides all but a 2^-28-rare case (j = l_0 / p_0 mod 2^28 must be below V);
+//     the rest is gathered, normalised exactly and compared with j p.
+// Same interface as FpZ towards LazyJac.  Device only (DPP); serves batch_exp, /root/reference/src/bin/contribute.rs:811-823.
+#pragma once
+#include "fpl.hpp"
+#include "fpz.hpp"
+
+namespace ptau {
+
+template <class P>
+struct FpLZ {
+    static constexpr int N = P::N;
+    static constexpr int H = N / 2;
+    static constexpr int LB = P::LB;
+    static constexpr uint32_t MASK = (1u << LB) - 1u;
+    using L29 = FpL<typename P::P29>;
+    using F29 = typename L29::Full;
+    static_assert(LB == 28 && N % 2 == 0 && L29::H == H, "written for the same limb count as the reduced lane-split form");
+    static_assert(LB * N >= F29::Params::BITS + 15, "R must exceed 2^15 p");
+    static_assert(2 * H * 17 < 512, "a slot of the accumulator row would overflow 64 bits");
+
+    PTAU_HD static bool hi_lane() { return lane_parity() != 0; }
+
+    template <int U, int V>
+    struct E {
+        static_assert(U >= 1 && U <= 15, "a limb would not fit 32 bits");
+        static_assert(V >= 1 && V <= (1 << 14), "the value would not stay below R");
+        uint32_t l[H];
+        template <int U2, int V2>
+        PTAU_HD operator E<U2, V2>() const {
+            static_assert(U2 >= U && V2 >= V, "bounds can only be loosened");
+            E<U2, V2> r;
+#pragma unroll
+            for (int i = 0; i < H; i++) r.l[i] = l[i];
+            return r;
+        }
+    };
+    using Nrm = E<1, 2>;
+
+    struct Limbs { uint32_t l[N]; };
+    // K p with every limb below the top raised by UB 2^28, borrowed from the next limb up (see FpZ::make_subc)
+    static constexpr Limbs make_subc(int K, int UB) {
+        Limbs r{};
+        uint64_t c = 0;
+        for (int i = 0; i < N; i++) {
+            const uint64_t t = (uint64_t)K * P::MOD[i] + c;
+            if (i < N - 1) {
+                r.l[i] = (uint32_t)(t & MASK) + ((uint32_t)UB << LB) - (i ? (uint32_t)UB : 0u);
+                c = t >> LB;
+            } else {
+                r.l[i] = (uint32_t)t - (uint32_t)UB;
+            }
+        }
+        return r;
+    }
+    template <int K, int UB>
+    struct SubC {
+        static_assert(UB <= 15, "bias does not fit a limb");
+        static constexpr Limbs v = make_subc(K, UB);
+    };
+    // this lane's half of a constant given as N limbs
+    PTAU_HD static uint32_t mine(const uint32_t *c, int j) { return hi_lane() ? c[H + j] : c[j]; }
+
+    template <int U1, int V1, int U2, int V2>
+    PTAU_HD static E<U1 + U2, V1 + V2> add(const E<U1, V1> &a, const E<U2, V2> &b) {
+        E<U1 + U2, V1 + V2> r;
+#pragma unroll
+        for (int i = 0; i < H; i++) r.l[i] = a.l[i] + b.l[i];
+        return r;
+    }
+    template <int U1, int V1, int U2, int V2>
+    PTAU_HD static E<U1 + U2 + 2, V1 + V2 + 1> sub(const E<U1, V1> &a, const E<U2, V2> &b) {
+        const bool hi = hi_lane();
+        E<U1 + U2 + 2, V1 + V2 + 1> r;
+#pragma unroll
+        for (int i = 0; i < H; i++) r.l[i] = a.l[i] + (hi ? SubC<V2 + 1, U2 + 1>::v.l[H + i] : SubC<V2 + 1, U2 + 1>::v.l[i]) - b.l[i];
+        return r;
+    }
+    template <int U, int V>
+    PTAU_HD static E<U + 2, V + 1> neg(const E<U, V> &a) {
+        const bool hi = hi_lane();
+        E<U + 2, V + 1> r;
+#pragma unroll
+        for (int i = 0; i < H; i++) r.l[i] = (hi ? SubC<V + 1, U + 1>::v.l[H + i] : SubC<V + 1, U + 1>::v.l[i]) - a.l[i];
+        return r;
+    }
+    template <int K, int U, int V>
+    PTAU_HD static E<K * U, K * V> times(const E<U, V> &a) {
+        static_assert(K == 2 || K == 3 || K == 4 || K == 8, "small multiples used by the point formulas");
+        E<K * U, K * V> r;
+#pragma unroll
+        for (int i = 0; i < H; i++) {
+            if constexpr (K == 2) r.l[i] = a.l[i] + a.l[i];
+            else if constexpr (K == 3) r.l[i] = a.l[i] + a.l[i] + a.l[i];
+            else if constexpr (K == 4) r.l[i] = a.l[i] << 2;
+            else r.l[i] = a.l[i] << 3;
+        }
+        return r;
+    }
+    // carries propagated inside each lane; the even lane's carry-out (< 16) is added to the odd lane's lowest limb as it is
+    template <int U, int V>
+    PTAU_HD static E<1, V> norm(const E<U, V> &a) {
+        const bool hi = hi_lane();
+        E<1, V> r;
+        uint32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < H - 1; i++) {
+            const uint32_t w = a.l[i] + c;
+            r.l[i] = w & MASK;
+            c = w >> LB;
+        }
+        const uint32_t w = a.l[H - 1] + c;
+        r.l[H - 1] = hi ? w : (w & MASK);
+        const uint32_t from_even = lane_xchg(w >> LB);
+        r.l[0] += hi ? from_even : 0u;
+        return r;
+    }
+
+    // ---- Montgomery product / square, accumulator row distributed over the pair (FpL::row_mul), carry-propagating tail ----
+    PTAU_HD static void row_finish(const uint64_t (&acc)[H], uint32_t (&out)[H]) {
+        const bool hi = hi_lane();
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < H - 1; j++) {
+            const uint64_t v = acc[j] + c;
+            out[j] = (uint32_t)v & MASK;
+            c = v >> LB;
+        }
+        const uint64_t vt = acc[H - 1] + c;
+        out[H - 1] = hi ? (uint32_t)vt : ((uint32_t)vt & MASK);   // odd lane: the value's top, below 2p / 2^(28 (N - 1))
+        const uint64_t co = vt >> LB;                            // even lane: carry into the odd lane's digits, < 2^36
+        const uint32_t clo = lane_xchg((uint32_t)co & MASK), chi = lane_xchg((uint32_t)(co >> LB));
+        const uint32_t w0 = out[0] + (hi ? clo : 0u);
+        out[0] = w0 & MASK;
+        out[1] += (hi ? chi : 0u) + (w0 >> LB);
+    }
+    PTAU_HD static void row_mul(const uint32_t (&a)[H], const uint32_t (&b)[H], uint32_t (&out)[H]) {
+        const bool hi = hi_lane();
+        uint32_t pm[H];
+#pragma unroll
+        for (int j = 0; j < H; j++) pm[j] = hi ? P::MOD[H + j] : P::MOD[j];
+        uint64_t acc[H];
+#pragma unroll
+        for (int j = 0; j < H; j++) acc[j] = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const uint32_t ai = i < H ? lane_bcast_even(a[i]) : lane_bcast_odd(a[i - H]);
+#pragma unroll
+            for (int j = 0; j < H; j++) mac64_vv(acc[j], ai, b[j]);
+            const uint32_t m = lane_bcast_even(((uint32_t)acc[0] * P::INV) & MASK);
+#pragma unroll
+            for (int j = 0; j < H; j++) mac64_vv(acc[j], m, pm[j]);
+            const uint64_t x = acc[0];
+            const uint32_t recv = lane_xchg((uint32_t)x & MASK);
+#pragma unroll
+            for (int j = 0; j + 1 < H; j++) acc[j] = acc[j + 1];
+            acc[0] += x >> LB;
+            acc[H - 1] = recv;
+        }
+        row_finish(acc, out);
+    }
+    PTAU_HD static void row_sqr(const uint32_t (&a)[H], uint32_t (&out)[H]) {
+        const bool hi = hi_lane();
+        uint32_t pm[H], az[H];
+#pragma unroll
+        for (int j = 0; j < H; j++) {
+            pm[j] = hi ? P::MOD[H + j] : P::MOD[j];
+            az[j] = hi ? a[j] : 0u;
+        }
+        const uint32_t dbl_odd = hi ? 1u : 0u;
+        uint64_t acc[H];
+#pragma unroll
+        for (int j = 0; j < H; j++) acc[j] = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            if (i < H) {
+                const uint32_t ai = lane_bcast_even(a[i]) << dbl_odd;
+#pragma unroll
+                for (int j = 0; j < H; j++) mac64_vv(acc[j], ai, a[j]);
+            } else {
+                const int d = i - H;
+                const uint32_t ai = lane_bcast_odd(a[d]);
+                mac64_vv(acc[d], ai, az[d]);
+                const uint32_t ai2 = ai << 1;
+#pragma unroll
+                for (int j = d + 1; j < H; j++) mac64_vv(acc[j], ai2, az[j]);
+            }
+            const uint32_t m = lane_bcast_even(((uint32_t)acc[0] * P::INV) & MASK);
+#pragma unroll
+            for (int j = 0; j < H; j++) mac64_vv(acc[j], m, pm[j]);
+            const uint64_t x = acc[0];
+            const uint32_t recv = lane_xchg((uint32_t)x & MASK);
+#pragma unroll
+            for (int j = 0; j + 1 < H; j++) acc[j] = acc[j + 1];
+            acc[0] += x >> LB;
+            acc[H - 1] = recv;
+        }
+        row_finish(acc, out);
+    }
+    typedef uint32_t VecH __attribute__((ext_vector_type(H)));
+    __device__ __noinline__ static VecH mul_vec(VecH a, VecH b) {
+        uint32_t x[H], y[H], r[H];
+#pragma unroll
+        for (int j = 0; j < H; j++) { x[j] = a[j]; y[j] = b[j]; }
+        row_mul(x, y, r);
+        VecH o;
+#pragma unroll
+        for (int j = 0; j < H; j++) o[j] = r[j];
+        return o;
+    }
+    __device__ __noinline__ static VecH sqr_vec(VecH a) {
+        uint32_t x[H], r[H];
+#pragma unroll
+        for (int j = 0; j < H; j++) x[j] = a[j];
+        row_sqr(x, r);
+        VecH o;
+#pragma unroll
+        for (int j = 0; j < H; j++) o[j] = r[j];
+        return o;
+    }
+    template <int U1, int V1, int U2, int V2>
+    PTAU_HD static Nrm mul(const E<U1, V1> &a, const E<U2, V2> &b) {
+        static_assert(U1 * U2 <= 16, "a slot of the product's row would overflow 64 bits: normalise an operand first");
+        static_assert(V1 * V2 <= (1 << 15), "the product would not come back below 2p");
+        Nrm r;
+#if defined(__HIP_DEVICE_COMPILE__)
+        VecH x, y;
+#pragma unroll
+        for (int j = 0; j < H; j++) { x[j] = a.l[j]; y[j] = b.l[j]; }
+        const VecH o = mul_vec(x, y);
+#pragma unroll
+        for (int j = 0; j < H; j++) r.l[j] = o[j];
+#else
+        (void)b;
+#pragma unroll
+        for (int j = 0; j < H; j++) r.l[j] = a.l[j];   // lane-split fields exist on the device only
+#endif
+        return r;
+    }
+    template <int U, int V>
+    PTAU_HD static Nrm sqr(const E<U, V> &a) {
+        static_assert(U * U <= 16 && U <= 7, "a slot of the square's row would overflow 64 bits: normalise the operand first");
+        static_assert(V * V <= (1 << 15), "the square would not come back below 2p");
+        Nrm r;
+#if defined(__HIP_DEVICE_COMPILE__)
+        VecH x;
+#pragma unroll
+        for (int j = 0; j < H; j++) x[j] = a.l[j];
+        const VecH o = sqr_vec(x);
+#pragma unroll
+        for (int j = 0; j < H; j++) r.l[j] = o[j];
+#else
+#pragma unroll
+        for (int j = 0; j < H; j++) r.l[j] = a.l[j];
+#endif
+        return r;
+    }
+
+    PTAU_HD static Nrm zero() {
+        Nrm r;
+#pragma unroll
+        for (int i = 0; i < H; i++) r.l[i] = 0;
+        return r;
+    }
+    PTAU_HD static Nrm one() {
+        Nrm r;
+#pragma unroll
+        for (int i = 0; i < H; i++) r.l[i] = mine(P::R1, i);
+        return r;
+    }
+    PTAU_HD static bool both(bool m) {
+        const uint32_t theirs = lane_xchg(m ? 1u : 0u);
+        return m && theirs != 0u;
+    }
+    // all N limbs of a value in both lanes
+    template <int U, int V>
+    PTAU_HD static void gather(const E<U, V> &a, uint32_t *f) {   // f: at least N entries
+        const bool hi = hi_lane();
+#pragma unroll
+        for (int j = 0; j < H; j++) {
+            const uint32_t o = lane_xchg(a.l[j]);
+            f[j] = hi ? o : a.l[j];
+            f[H + j] = hi ? a.l[j] : o;
+        }
+    }
+    template <int V>
+    PTAU_HD static bool is_zero(const E<1, V> &a) {
+        const uint32_t l0 = lane_bcast_even(a.l[0]);
+        const uint32_t j = (0u - l0 * P::INV) & MASK;   // l_0 / p_0 mod 2^28: the only multiple of p it can be is j p
+        if (j >= (uint32_t)V) return false;
+        uint32_t f[N];
+        gather(a, f);
+        uint32_t c = 0, diff = 0;
+        uint64_t pc = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const uint32_t w = f[i] + c;
+            const uint64_t t = (uint64_t)j * P::MOD[i] + pc;
+            diff |= (i < N - 1 ? (w & MASK) : w) ^ (i < N - 1 ? (uint32_t)(t & MASK) : (uint32_t)t);
+            c = w >> LB;
+            pc = t >> LB;
+        }
+        return diff == 0;
+    }
+    template <int U, int V>
+    PTAU_HD static bool limbs_all_zero(const E<U, V> &a) {
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < H; i++) o |= a.l[i];
+        return both(o == 0);
+    }
+
+    // FpL (29-bit limbs, fully reduced) <-> this representation; off the hot path: through the whole element in each lane
+    PTAU_HD static Nrm from29(const L29 &a) {
+        const bool hi = hi_lane();
+        const F29 f = a.gather();
+        E<1, 1> t, c;
+#pragma unroll
+        for (int k = 0; k < H; k++) {
+            uint32_t half[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int bit = LB * (h * H + k), s = bit / 29, o = bit % 29;
+                uint32_t v = s < F29::N ? f.l[s] >> o : 0u;
+                if (o + LB > 29 && s + 1 < F29::N) v |= f.l[s + 1] << (29 - o);
+                half[h] = v & MASK;
+            }
+            t.l[k] = hi ? half[1] : half[0];
+            c.l[k] = mine(P::FROM29, k);
+        }
+        return mul(t, c);
+    }
+    template <int U, int V>
+    PTAU_HD static L29 to29(const E<U, V> &a) {
+        E<1, 1> c;
+#pragma unroll
+        for (int k = 0; k < H; k++) c.l[k] = mine(P::TO29, k);
+        const Nrm v = mul(a, c);
+        uint32_t f[N + 1], u[N];
+        gather(v, f);
+        // exact digits, then one conditional subtraction (the value is below 2p)
+        uint32_t cc = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const uint32_t w = f[i] + cc;
+            f[i] = i < N - 1 ? (w & MASK) : w;
+            cc = i < N - 1 ? (w >> LB) : 0u;
+        }
+        int32_t cy = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const int32_t w = (int32_t)f[i] - (int32_t)P::MOD[i] + cy;
+            cy = w >> LB;
+            u[i] = i < N - 1 ? ((uint32_t)w & MASK) : (uint32_t)w;
+        }
+#pragma unroll
+        for (int i = 0; i < N; i++) f[i] = cy < 0 ? f[i] : u[i];
+        f[N] = 0;
+        F29 r;
+#pragma unroll
+        for (int k = 0; k < F29::N; k++) {
+            const int bit = 29 * k, s = bit / LB, o = bit % LB;
+            uint32_t w = s < N ? f[s] >> o : 0u;
+            if (s + 1 <= N) w |= f[s + 1] << (LB - o);
+            r.l[k] = w & F29::MASK;
+        }
+        return L29::scatter(r);
+    }
+};
+
+}  // namespace ptau

@@ -23,7 +23,7 @@ RADIX29 = {"BlsFq", "Mnt4Fq", "Mnt6Fq", "Bw6Fq"}
 # BW6-761 (round 2): 28 limbs of 29 bits — one more than ceil(761 / 29) — so that the element splits evenly over a lane pair
 # (fpl.hpp); its single-lane kernels (verify path) use the same representation so both kinds of kernel exchange values limb for limb.
 RADIX29_LIMBS = {"Bw6Fq": 28}
-LAZY28 = {"BlsFq"}      # base fields that also get a carry-free 28-bit twin (fpz.hpp)
+LAZY28 = {"BlsFq", "Bw6Fq"}      # base fields that also get a carry-free 28-bit twin (fpz.hpp; lane-split: fplz.hpp)
 
 
 # The MNT twists' G2 generators are NOT here: ark-mnt4-753 / ark-mnt6-753's constants are not recoverable offline, so the
@@ -221,10 +221,11 @@ def main():
     # carry-free ("lazy") twin of a base field for the inner loop of K1 (fpz.hpp): 28-bit limbs, one limb more than the
     # modulus needs, so that R = 2^(28 N) >= 2^15 p: sums and differences of a few elements stay valid operands of a product
     # (no carry chain, no conditional subtraction) and a product brings any such operand back below 2p.
+    lazy_twins = []
     for name, p in ((nm, fields[nm][0]) for nm in sorted(LAZY28)):
         lb, n = 28, (p.bit_length() + 15 + 27) // 28
         Rz, R29 = 1 << (lb * n), fields[name + "R29"][2]
-        assert Rz >= p << 15 and p % (1 << lb) == 1      # p = 1 mod 2^28: m_i = -acc mod 2^28, m_i p_0 is an addition
+        assert Rz >= p << 15      # (BLS12-377: p = 1 mod 2^28, so m_i = -acc mod 2^28 and m_i p_0 is an addition)
         out.append("struct %sZ28 {" % name)
         out.append("  static constexpr int LB = %d;" % lb)
         out.append("  static constexpr int N = %d;" % n)
@@ -235,8 +236,10 @@ def main():
         out.append("  static constexpr uint32_t TO29[%d] = {%s};     // R29 mod p: (x Rz) -> (x R29)" % (n, limbs(R29 % p, n, lb)))
         out.append("  using P29 = %sR29;" % name)
         out.append("};")
-        out.append("template <class P> struct LazyTwin { using type = void; };")
-        out.append("template <> struct LazyTwin<%sR29> { using type = %sZ28; };" % (name, name))
+        lazy_twins.append((name + "R29", name + "Z28"))
+    out.append("template <class P> struct LazyTwin { using type = void; };")
+    for a, b in lazy_twins:
+        out.append("template <> struct LazyTwin<%s> { using type = %s; };" % (a, b))
     fq_of = lambda base: base + "R29" if base in RADIX29 else base   # the struct a curve over `base` is generated for
     out.append("using Bw6Fr = BlsFq;")
     out.append("using Mnt4Fr = Mnt6Fq;")

@@ -22,6 +22,7 @@
 
 #include "ec.hpp"
 #include "fpz.hpp"
+#include "fplz.hpp"
 
 #ifndef PTAU_G1_MIN_WAVES
 #define PTAU_G1_MIN_WAVES 2
@@ -53,6 +54,12 @@ constexpr int SCALAR_TABLE_ENTRIES = 64;   // tau^(2^k), k < 64, preceded by the
 // per lane (Fp2L, ext.hpp: BLS12-377 G2); every base-field element over a lane pair, half of the limbs per lane (FpL,
 // fpl.hpp: the 26-28-limb fields of MNT4/MNT6-753 and BW6-761).  The last two run two threads per point.
 enum : int { LANES_ONE = 0, LANES_FQ2_PAIR = 1, LANES_LIMB_SPLIT = 2 };
+
+// A carry-free twin field usable with one lane per element (FpZ): 14 limbs, p = 1 mod 2^28.
+template <class P>
+struct LazyOneLane { static constexpr bool value = P::N <= 14 && P::MOD[0] == 1u; };
+template <>
+struct LazyOneLane<void> { static constexpr bool value = false; };
 
 // Host+device view of one group's types.
 template <class FqP, class FrP, class Cfg, int LANE_MODE_ = LANES_ONE>
@@ -95,7 +102,9 @@ struct GroupTypes {
 #endif
     using LazyP = typename LazyTwin<FqP>::type;
     static constexpr bool LAZY_LOOP = PTAU_LAZY_LOOP && AFFINE_TABLE && !std::is_void<LazyP>::value &&
-                                      ((LANE_MODE == LANES_ONE && F::DEG == 1) || (LANE_MODE == LANES_FQ2_PAIR && F::DEG == 2));
+                                      ((LANE_MODE == LANES_ONE && F::DEG == 1 && LazyOneLane<LazyP>::value) ||
+                                       (LANE_MODE == LANES_FQ2_PAIR && F::DEG == 2 && LazyOneLane<LazyP>::value) ||
+                                       (LANE_MODE == LANES_LIMB_SPLIT && F::DEG == 1));
     static constexpr int MIN_WAVES = LANE_MODE == LANES_LIMB_SPLIT ? PTAU_SPLIT_MIN_WAVES : LPP == 2 ? PTAU_LANE_MIN_WAVES : SMALL ? PTAU_G1_MIN_WAVES : (PTAU_MIN_WAVES_WIDE > 0 ? PTAU_MIN_WAVES_WIDE : 1);
 };
 
@@ -464,13 +473,14 @@ PTAU_HD void store_jac(typename G::J *scratch, uint64_t i, const typename G::J &
 template <class G>
 struct LazyOf {
     using F = typename G::F;
-    using LZ = FpZ<typename G::LazyP>;
-    static constexpr bool PAIR = F::DEG == 2;
+    static constexpr bool PAIR = F::DEG == 2;                            // Fq2 over a lane pair, FpZ coefficients
+    static constexpr bool SPLIT = G::LANE_MODE == LANES_LIMB_SPLIT;      // a wide prime field split over a lane pair
+    using LZ = std::conditional_t<SPLIT, FpLZ<typename G::LazyP>, FpZ<typename G::LazyP>>;
     using K = std::conditional_t<PAIR, Fp2Z<LZ, G::J::CfgT::NR>, LZ>;
     using Acc = std::conditional_t<PAIR, LazyJac2<K>, LazyJac<LZ>>;
     using AX = typename Acc::AX;
     using AY = typename Acc::AY;
-    static constexpr int N = LZ::N;
+    static constexpr int N = SPLIT ? LZ::N / 2 : LZ::N;                  // limbs held by one lane
     PTAU_HD static AX to_lazy(const F &x) {
         if constexpr (PAIR) return {LZ::from29(x.c)};
         else return LZ::from29(x);
