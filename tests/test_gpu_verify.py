@@ -484,3 +484,52 @@ print("ok", hashlib.blake2b(b"".join(out)).hexdigest()[:16])
 ''' % (ROOT, ROOT))
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.startswith("ok"), r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,group", [("bls12_377", 1), ("bls12_377", 2), ("bw6", 1), ("bw6", 2)])
+def test_small_order_points_through_the_window_loops(name, group, pkg, cref):
+    """The window loops of these groups run in the carry-free fields (fpz.hpp, fplz.hpp): the exceptional cases — a table
+    multiple that is O, an addition that meets its own operand or its negative, the doubling of a 2-torsion point — are
+    decided by residue tests on unreduced values (over a lane pair for G2 and BW6-761).  Points of every small prime-power
+    order the cofactor offers, sums of them with subgroup points, and the identity, against the oracle's double-and-add."""
+    from oracle.pyref import keygen as K
+    c = CURVES[name]
+    G = Group(c, group)
+    rng = random.Random(90 + group)
+    h = K._cofactor(G)
+    F = G.F
+    def random_curve_point():
+        while True:
+            x = tuple(rng.randrange(c.q) for _ in range(F.deg))
+            y = F.sqrt(F.add(F.add(F.mul(F.sqr(x), x), F.mul(G.a, x)), G.b))
+            if y is not None:
+                return (x, y)
+    small = []
+    for ell in (2, 3, 5, 7, 11, 13, 17, 19):
+        k = 0
+        while h % ell ** (k + 1) == 0:
+            k += 1
+        if not k:
+            continue
+        for _ in range(4):   # a point of order ell^j, j >= 1, and its multiples down to order ell
+            T = G.mul(G.mul(random_curve_point(), c.r), h // ell ** k)
+            chain = []
+            while T is not None and len(chain) < 64:
+                chain.append(T)
+                T = G.mul(T, ell)
+            if chain:
+                small += chain[-3:]
+                break
+    if not small:   # BLS12-377 G2: the cofactor has no prime factor below 2 * 10^5 — cofactor-only points of large order instead
+        small = [G.mul(random_curve_point(), c.r) for _ in range(2)]
+    good = [G.mul(G.gen, rng.randrange(1, c.r)) for _ in range(3)]
+    pts = small + [None] + [G.add(good[i % 3], small[i % len(small)]) for i in range(3)] + good
+    n = len(pts)
+    data = serde.write_batch(G, pts, False)
+    for start, tau, coeff in ((0, rng.randrange(c.r), None), (3, 1, int("8" * 60, 16) % c.r), (0, 1, 1 << 200), (7, c.r - 1, rng.randrange(c.r)),
+                              (0, 2, 15), (5, 0, None)):
+        exp = cref.apply_powers(name, group, data, n, start, tau, coeff, False, False)
+        for mode in (pkg.BatchExpMode.Auto, pkg.BatchExpMode.Direct):
+            got = pkg.phase1_cli.apply_powers(name, group, data, n, start, tau, coeff, False, False, batch_exp_mode=mode)
+            assert got == exp, (name, group, start, tau, coeff, mode)
