@@ -168,7 +168,7 @@ def whole_chunk_extras(pkg, curve, power, log2n, dev):
         # library serialises only the device section of a call, so one lane's BLAKE2b overlaps another lane's kernels
         import threading
         Lb = pkg.load_library()
-        for lanes in (1, 2, 3, 4):
+        for lanes in (1, 2, 3, 4, 6, 8):
             def lane_verify(k):
                 pkg.transform_pok_and_correctness(f("c0"), f("L%d.c.hash" % k), pkg.CheckForCorrectness.No, f("r0"), f("L%d.r.hash" % k),
                                                   pkg.CheckForCorrectness.OnlyNonZero, f("L%d.c1" % k), f("L%d.c1.hash" % k),

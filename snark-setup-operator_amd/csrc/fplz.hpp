@@ -26,6 +26,7 @@ struct FpLZ {
     using F29 = typename L29::Full;
     static_assert(LB == 28 && N % 2 == 0 && L29::H == H, "written for the same limb count as the reduced lane-split form");
     static_assert(LB * N >= F29::Params::BITS + 15, "R must exceed 2^15 p");
+    static_assert(P::MOD[N - 1] >= 16, "the biased multiples of p (SubC) borrow up to 15 from p's top limb");
     static_assert(2 * H * 17 < 512, "a slot of the accumulator row would overflow 64 bits");
 
     PTAU_HD static bool hi_lane() { return lane_parity() != 0; }

@@ -33,6 +33,7 @@ struct FpZ {
     using F29 = Fp29<typename P::P29>;
     static_assert(LB == 28 && P::MOD[0] == 1u && P::INV == MASK, "written for p = 1 mod 2^28");
     static_assert(LB * N >= F29::Params::BITS + 15, "R must exceed 2^15 p");
+    static_assert(P::MOD[N - 1] >= 16, "the biased multiples of p (SubC) borrow up to 15 from p's top limb");
 
     template <int U, int V>
     struct E {
