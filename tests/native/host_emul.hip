@@ -70,7 +70,7 @@ static int run(const std::string &op, uint64_t n, uint64_t start, int cin, int c
         // per pair (a, b): a+b | a-b | a*b | a^2 | -a | 5a - 8b (unnormalised operands into a product by 1) |
         //                  vreduce(31 a + 19 b ... as the point formulas stack them) | flags byte: bit0 is_zero(a - a), bit1
         //                  is_zero(a - b), bit2 is_zero(of 33 p built from limbs), bit3 is_zero(a) on the normalised value
-        if constexpr (!std::is_void<typename G::LazyP>::value && G::F::DEG == 1) {
+        if constexpr (LazyOneLane<typename G::LazyP>::value && G::F::DEG == 1) {   // the lane-split twin (fplz.hpp) is device-only
             using Fq = typename G::Fq;
             using Z = FpZ<typename G::LazyP>;
             const int B = Fq::BYTES;
