@@ -110,8 +110,9 @@ int ptau_fr_limbs(int curve);
 
 /* setup_utils::calculate_hash — src/bin/verify_transcript.rs:344-345, src/utils.rs:618-623 (host CPU) */
 void ptau_blake2b512(const uint8_t *data, size_t len, uint8_t out[64]);
-/* Which compression function the host BLAKE2b uses: 0 portable, 1 AVX2 (chosen at run time).  force = 0 / 1 selects one
- * (test hook: both are checked against each other and hashlib), force < 0 only reports. */
+/* Which compression function the host BLAKE2b uses: 0 portable, 1 AVX2, 2 BMI2-compiled scalar, 3 AVX-512 (timed against each
+ * other on first use).  force = 0..3 selects one if the CPU has it (test hook: all are checked against hashlib), force < 0
+ * only reports. */
 int ptau_blake2b_implementation(int force);
 
 /* setup-utils apply_powers = read_batch -> generate_powers_of_tau -> batch_exp -> write_batch

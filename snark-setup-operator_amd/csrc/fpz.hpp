@@ -360,20 +360,11 @@ struct LazyJac {
 
     // madd-2007-bl with Z3 = 2 Z1 H; q = (x2, y2) affine and not the point at infinity
     PTAU_HD static LazyJac add_mixed(const LazyJac &p, const AX &x2, const AY &y2) {
-#ifdef PTAU_LAZY1_EARLY_RETURN
-        if (p.is_inf()) return {x2, Z::norm(y2), Z::one()};
-#endif
         const auto Z1Z1 = Z::sqr(p.Zc);
         const auto U2 = Z::mul(x2, Z1Z1);
         const auto S2 = Z::mul(Z::mul(y2, p.Zc), Z1Z1);
         const auto H = Z::norm(Z::sub(U2, p.X));
         const auto rh = Z::norm(Z::sub(S2, p.Y));
-#ifdef PTAU_LAZY1_EARLY_RETURN
-        if (Z::is_zero(H)) {
-            if (Z::is_zero(rh)) return dbl(p);
-            return infinity();
-        }
-#endif
         const auto rr = Z::template times<2>(rh);
         const auto HH = Z::sqr(H);
         const auto I = Z::template times<4>(HH);
@@ -383,15 +374,14 @@ struct LazyJac {
         r.X = Z::norm(Z::sub(Z::sqr(rr), Z::add(J, Z::template times<2>(Vv))));
         r.Y = Z::norm(Z::sub(Z::mul(rr, Z::sub(Vv, r.X)), Z::template times<2>(Z::mul(p.Y, J))));
         r.Zc = Z::mul(Z::template times<2>(p.Zc), H);
-#ifndef PTAU_LAZY1_EARLY_RETURN
-        // the exceptional cases (p = O, q = +-p) overwrite the generic result: one join, rare path
+        // the exceptional cases (p = O, q = +-p) overwrite the generic result: one join, rare path (with early returns the
+        // accumulator went through scratch memory in the one-lane kernel; on the lane-split field the two forms time the same)
         const bool pinf = p.is_inf();
         if (pinf || Z::is_zero(H)) {
             if (pinf) r = {x2, Z::norm(y2), Z::one()};
             else if (Z::is_zero(rh)) r = dbl(p);
             else r = infinity();
         }
-#endif
         return r;
     }
 };

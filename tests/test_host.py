@@ -43,13 +43,14 @@ def test_host_blake2b(pkg, cref):
 
 
 def test_blake2b_portable_and_avx2_agree(pkg):
-    """The compression functions of the host BLAKE2b (portable, AVX2, BMI2-compiled scalar) against hashlib, on block-boundary lengths."""
+    """The compression functions of the host BLAKE2b (portable, AVX2, BMI2-compiled scalar, AVX-512) against hashlib, on
+    block-boundary lengths (a form the CPU lacks falls back to the chosen one)."""
     import hashlib
     L = pkg.load_library()
     chosen = L.ptau_blake2b_implementation(-1)
     data = bytes((i * 131 + 7) & 0xFF for i in range(70001))
     try:
-        for impl in (0, 1, 2):
+        for impl in (0, 1, 2, 3):
             L.ptau_blake2b_implementation(impl)
             for n in (0, 1, 127, 128, 129, 255, 256, 257, 4096, 70001):
                 assert pkg.calculate_hash(data[:n]) == hashlib.blake2b(data[:n]).digest(), (impl, n)
