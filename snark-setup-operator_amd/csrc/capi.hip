@@ -730,7 +730,17 @@ struct MappedFile {
         if (p != MAP_FAILED) munmap(p, len);
         if (fd >= 0) close(fd);
     }
-    int open_ro(const char *path, const Err &err) {
+    static bool want_register() {
+        static const bool w = [] {
+            const char *e = getenv("PTAU_HOST_REGISTER");
+            return !(e && e[0] == '0');
+        }();
+        return w;
+    }
+    // pin: the mapping feeds H2D copies of hundreds of MB — its pages are faulted in and registered with the HIP runtime
+    // (read-only registration) on a host thread, so that the copies are DMA from the file's pages instead of a staged
+    // pageable copy (12 GB/s and a busy host core inside the device section); wait_pinned() before the first copy.
+    int open_ro(const char *path, const Err &err, bool pin = false, int device = 0) {
         fd = open(path, O_RDONLY);
         if (fd < 0) return err.fail(PTAU_E_IO, "cannot open %s: %s", path, strerror(errno));
         struct stat st;
@@ -739,10 +749,24 @@ struct MappedFile {
         if (len) {
             p = mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
             if (p == MAP_FAILED) return err.fail(PTAU_E_IO, "cannot mmap %s: %s", path, strerror(errno));
+            if (pin && want_register()) {
+                populate = std::async(std::launch::async, [this, device] {
+#ifndef MADV_POPULATE_READ
+#define MADV_POPULATE_READ 22
+#endif
+                    if (madvise(p, len, MADV_POPULATE_READ) != 0) return;
+                    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return; }   // register in the caller's device context
+                    if (hipHostRegister(p, len, hipHostRegisterPortable | hipHostRegisterReadOnly) == hipSuccess) registered = true;
+                    else (void)hipGetLastError();
+                });
+            }
         }
         return PTAU_OK;
     }
-    int create_new(const char *path, size_t size, const Err &err) {
+    void wait_pinned() {
+        if (populate.valid()) populate.wait();
+    }
+    int create_new(const char *path, size_t size, const Err &err, int device = 0) {
         fd = open(path, O_RDWR | O_CREAT | O_EXCL, 0644);   // create_new semantics (contribute.rs:791-792)
         if (fd < 0) return err.fail(PTAU_E_IO, "cannot create %s: %s", path, strerror(errno));
         if (ftruncate(fd, (off_t)size)) return err.fail(PTAU_E_IO, "cannot size %s: %s", path, strerror(errno));
@@ -755,16 +779,14 @@ struct MappedFile {
         // computing — MADV_POPULATE_WRITE does not modify their content, so it may run beside the copies — and the
         // populated range is then page-locked and registered with the HIP runtime (DMA straight into the file's pages,
         // no bounce buffer) unless PTAU_HOST_REGISTER=0.
-        populate = std::async(std::launch::async, [this] {
+        populate = std::async(std::launch::async, [this, device] {
 #ifndef MADV_POPULATE_WRITE
 #define MADV_POPULATE_WRITE 23
 #endif
             if (madvise(p, len, MADV_POPULATE_WRITE) != 0) return;
-            static const bool want_register = [] {
-                const char *e = getenv("PTAU_HOST_REGISTER");
-                return !(e && e[0] == '0');
-            }();
-            if (want_register && hipHostRegister(p, len, hipHostRegisterPortable) == hipSuccess) registered = true;
+            if (!want_register()) return;
+            if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return; }   // register in the caller's device context
+            if (hipHostRegister(p, len, hipHostRegisterPortable) == hipSuccess) registered = true;
             else (void)hipGetLastError();
         });
         return PTAU_OK;
@@ -983,17 +1005,18 @@ int ptau_contribute_file(const ptau_params *p, const char *challenge_path, const
         return err.fail(PTAU_E_LEN, "public key is %zu bytes, expected %llu", public_key_len,
                         (unsigned long long)sz.public_key_size);
     MappedFile ch, resp;
-    if ((rc = ch.open_ro(challenge_path, err))) return rc;
+    if ((rc = ch.open_ro(challenge_path, err, /*pin=*/true, device))) return rc;
     if (ch.len != sz.accumulator_size)
         return err.fail(PTAU_E_LEN, "challenge file is %zu bytes, parameters require %llu", ch.len,
                         (unsigned long long)sz.accumulator_size);
     uint8_t digest[64];
-    if ((rc = resp.create_new(response_path, sz.contribution_size, err))) return rc;
+    if ((rc = resp.create_new(response_path, sz.contribution_size, err, device))) return rc;
     uint8_t *out = (uint8_t *)resp.p;
     {   // BLAKE2b(challenge) on a host thread while the GPU updates the elements
         const uint8_t *chp = (const uint8_t *)ch.p;
         const size_t chl = ch.len;
         auto fut = std::async(std::launch::async, [chp, chl, &digest] { ptau_blake2b512(chp, chl, digest); });
+        ch.wait_pinned();
         rc = ptau_phase1_computation(p, chp, chl, out, resp.len, tau, alpha, beta, check_input, batch_exp_mode, device, errbuf, err_len);
         fut.get();
         if (rc) return rc;
@@ -1021,11 +1044,11 @@ int ptau_contribute_file_seeded(const ptau_params *p, const char *challenge_path
     uint64_t tau[12], alpha[12], beta[12];
     if ((rc = ptau_private_key_from_seed(p->curve, seed, seed_len, tau, alpha, beta, errbuf, err_len))) return rc;
     MappedFile ch, resp;
-    if ((rc = ch.open_ro(challenge_path, err))) return rc;
+    if ((rc = ch.open_ro(challenge_path, err, /*pin=*/true, device))) return rc;
     if (ch.len != sz.accumulator_size)
         return err.fail(PTAU_E_LEN, "challenge file is %zu bytes, parameters require %llu", ch.len,
                         (unsigned long long)sz.accumulator_size);
-    if ((rc = resp.create_new(response_path, sz.contribution_size, err))) return rc;
+    if ((rc = resp.create_new(response_path, sz.contribution_size, err, device))) return rc;
     uint8_t *out = (uint8_t *)resp.p;
     uint8_t digest[64];
     std::vector<uint8_t> pk(sz.public_key_size);
@@ -1039,6 +1062,7 @@ int ptau_contribute_file_seeded(const ptau_params *p, const char *challenge_path
             uint64_t t2[12], a2[12], b2[12];
             return ptau_key_generation(curve, seed, seed_len, digest, t2, a2, b2, pk.data(), pk.size(), kmsg, sizeof(kmsg));
         });
+        ch.wait_pinned();
         rc = ptau_phase1_computation(p, chp, chl, out, resp.len, tau, alpha, beta, check_input, batch_exp_mode, device, errbuf, err_len);
         const int krc = fut.get();
         if (rc) return rc;
@@ -1447,12 +1471,13 @@ int ptau_transform_pok_and_correctness_file(const ptau_params *p, const char *ch
     ptau_params_sizes(p, &sz);
     MappedFile ch, resp, nc;
     if ((rc = ch.open_ro(challenge_path, err))) return rc;
-    if ((rc = resp.open_ro(response_path, err))) return rc;
+    if ((rc = resp.open_ro(response_path, err, /*pin=*/true, device))) return rc;
     if (ch.len != sz.accumulator_size || resp.len != sz.contribution_size)
         return err.fail(PTAU_E_LEN, "challenge/response file sizes %zu/%zu do not match the parameters (%llu/%llu)", ch.len,
                         resp.len, (unsigned long long)sz.accumulator_size, (unsigned long long)sz.contribution_size);
-    if ((rc = nc.create_new(new_challenge_path, sz.accumulator_size, err))) return rc;
+    if ((rc = nc.create_new(new_challenge_path, sz.accumulator_size, err, device))) return rc;
     VerifyDigests dg;
+    resp.wait_pinned();
     rc = verify_chunk_impl(p, (const uint8_t *)ch.p, ch.len, (const uint8_t *)resp.p, resp.len, (uint8_t *)nc.p, nc.len, check_input,
                            check_output, subgroup_check_mode, ratio_check, /*verify_pok=*/1, g2_s, nullptr, device, &dg, errbuf, err_len);
     // the reference writes challenge.hash and response.hash before it verifies: keep them on the failure paths that got that far
