@@ -314,6 +314,9 @@ def main():
     ap.add_argument("--log2-points", type=int, default=None, help="override the vector length of the config")
     ap.add_argument("--cpu-sample", type=int, default=None, help="points the CPU oracle updates (parity check + cpu_baseline)")
     ap.add_argument("--no-extras", action="store_true", help="skip the whole-chunk contribute / verify measurements")
+    ap.add_argument("--exact-only", action="store_true",
+                    help="launch the exact path only (no endomorphism-path lines): under rocprofv3 every launch of the kernel is then "
+                         "the one `value` and `roofline` describe, so the profile's per-kernel averages are comparable to them")
     args = ap.parse_args()
 
     import torch
@@ -402,7 +405,7 @@ def main():
     # the same step on the endomorphism path (membership asserted by the caller — what an operator that trusts its
     # coordinator's verifier runs): reported next to `value`, never as `value`
     endo = None
-    if not curve.startswith("mnt"):
+    if not curve.startswith("mnt") and not args.exact_only:
         run(d_chal, 0, d_resp, 1, tau, ENDO)
         endo_ms = 0.0
         te = time.perf_counter()
@@ -484,7 +487,7 @@ def main():
                      "hbm_frac": 3 * cs2 * n2 / (t2["scalar_mul_ms"] / 1e3) / 1e9 / HBM_PEAK_GBS,
                      "alu_frac": (m2 * n2 / (t2["scalar_mul_ms"] / 1e3) / MAC_PEAK) if m2 else None,
                      "traffic_ratio": (p2["hbm_bytes_per_launch"] / (3 * cs2 * n2)) if p2 else None}
-            if not c2.startswith("mnt"):
+            if not c2.startswith("mnt") and not args.exact_only:
                 run2(dc, 0, dr, 1, tau, ENDO)
                 entry["endomorphism_updates_per_s"] = n2 / (pkg.phase1_cli.last_timing(dev)["kernel_ms"] / 1e3)
             others["%s_G%d" % (c2, g2)] = entry

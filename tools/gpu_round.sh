@@ -19,7 +19,8 @@ if [ "${SKIP_BENCH:-0}" != "1" ]; then
 fi
 cd /tmp
 for cfg in $CONFIGS; do
-  BARGS="--config $cfg --steps 2 --warmup 1 --no-extras --cpu-sample 512"
+  # --exact-only: every launch the profiler sees is the path `value` / `roofline` describe (the endomorphism path runs the same kernel)
+  BARGS="--config $cfg --steps 2 --warmup 1 --no-extras --cpu-sample 512 --exact-only"
   timeout -k 10 400 python3 $R/bench.py --config $cfg --steps 3 --warmup 1 --no-extras --cpu-sample 4096 > $R/$OUT/bench_cfg$cfg.json 2> $R/$OUT/bench_cfg$cfg.err || { tail -20 $R/$OUT/bench_cfg$cfg.err; exit 1; }
   timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $R/$OUT/stats_cfg$cfg -o stats --output-format csv -- python3 $R/bench.py $BARGS > $R/$OUT/stats_cfg$cfg.log 2>&1 || { tail -5 $R/$OUT/stats_cfg$cfg.log; exit 1; }
   for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "GRBM_GUI_ACTIVE"; do
