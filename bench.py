@@ -378,7 +378,7 @@ def main():
                                          n, start, pkg._lib.limbs(tau, nl), None, 0, mode, dev, eb, len(eb))
             if rc:
                 raise RuntimeError("ptau_apply_powers_dev rc=%d: %s" % (rc, eb.value.decode()))
-        run(d_gen, 0, d_chal, 0, s, ENDO)
+        run(d_gen, 0, d_chal, 0, s, 0 if args.exact_only else ENDO)   # the challenge vector itself: s^i * generator
         del d_gen
         return d_chal, d_resp, run, usz, csz
 
