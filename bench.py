@@ -219,7 +219,7 @@ def whole_chunk_extras(pkg, curve, power, log2n, dev):
 #  kernels hold it, extension degree, GLV/GLS available).  Algorithmic bytes per update = uncompressed read + compressed
 # write = 3 x the compressed size: 144 / 288 / 285 / 570 / 855 B.
 CONFIGS = {
-    2: {"groups": [("bls12_377", 1, 20)], "power": 20, "log2_chunk": 20,
+    2: {"groups": [("bls12_377", 1, 20), ("bls12_377", 2, 20)], "power": 20, "log2_chunk": 20,
         "workload": "BLS12-377 phase-1 power 20, chunk_size 2^20: tauG1 vector of one chunk per GPU"},
     3: {"groups": [("bw6", 1, 18), ("bw6", 2, 18)], "power": 20, "log2_chunk": 18,
         "workload": "BW6-761 phase-1 power 20, chunk_size 2^18 (8 chunks, one per GPU): tauG1 vector of one chunk per GPU"},

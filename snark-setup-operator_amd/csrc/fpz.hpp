@@ -495,13 +495,13 @@ struct Fp2Z {
     PTAU_HD static bool limbs_all_zero(const E<U, V> &a) { return both(Z::limbs_all_zero(a.c)); }
 };
 
-// Jacobian arithmetic on y^2 = x^3 + b' over Fp2Z (a = 0).  Coordinates between operations: X and Y reduced below 3p, Z a
-// product (below 13p), all normalised; every intermediate bound is in the types.
+// Jacobian arithmetic on y^2 = x^3 + b' over Fp2Z (a = 0).  Coordinates between operations: X and Y reduced below 3p, Z
+// below 31p, all normalised; every intermediate bound is in the types.
 template <class K>
 struct LazyJac2 {
     using XT = typename K::R;
     using YT = typename K::R;
-    using ZT = typename K::M;
+    using ZT = typename K::template E<1, 31>;   // a product (doubling) or Z1 + H squared minus two squares (addition)
     using AX = typename K::template E<1, 2>;   // affine x of a table entry (possibly after psi^j)
     using AY = typename K::template E<3, 3>;   // affine y, possibly negated on the fly
     XT X;
@@ -545,7 +545,8 @@ struct LazyJac2 {
         LazyJac2 r;
         r.X = K::reduce(K::sub(R2, K::add(J, K::template times<2>(Vv))));
         r.Y = K::reduce(K::sub(K::mul(K::template times<2>(rh), K::sub(Vv, r.X)), K::template times<2>(K::mul(p.Y, J))));
-        r.Zc = K::mul(K::template times<2>(p.Zc), H);
+        // Z3 = (Z1 + H)^2 - Z1^2 - H^2: a square is ONE base product per lane where the product 2 Z1 H is two
+        r.Zc = K::norm(K::sub(K::sqr(K::norm(K::add(p.Zc, H))), K::add(Z1Z1, HH)));
         return r;
     }
 };
