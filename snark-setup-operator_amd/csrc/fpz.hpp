@@ -502,8 +502,8 @@ struct LazyJac2 {
     using XT = typename K::R;
     using YT = typename K::R;
     using ZT = typename K::template E<1, 31>;   // a product (doubling) or Z1 + H squared minus two squares (addition)
-    using AX = typename K::template E<1, 2>;   // affine x of a table entry (possibly after psi^j)
-    using AY = typename K::template E<3, 3>;   // affine y, possibly negated on the fly
+    using AX = typename K::M;                   // affine x of a table entry (a product; possibly after psi^j)
+    using AY = typename K::template E<3, 14>;   // affine y, possibly negated on the fly
     XT X;
     YT Y;
     ZT Zc;
@@ -527,7 +527,7 @@ struct LazyJac2 {
     }
     // q = (x2, y2) affine, not the point at infinity
     PTAU_HD static LazyJac2 add_mixed(const LazyJac2 &p, const AX &x2, const AY &y2) {
-        if (p.is_inf()) return {x2, K::norm(y2), K::one()};
+        if (p.is_inf()) return {K::reduce(x2), K::reduce(y2), K::one()};
         const auto Z1Z1 = K::sqr(p.Zc);
         const auto U2 = K::mul(x2, Z1Z1);
         const auto S2 = K::mul(K::mul(y2, p.Zc), Z1Z1);

@@ -19,6 +19,7 @@
 #pragma once
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 #include "ec.hpp"
 #include "fpz.hpp"
@@ -470,6 +471,11 @@ PTAU_HD void store_jac(typename G::J *scratch, uint64_t i, const typename G::J &
 
 // The carry-free field of a group (named only under G::LAZY_LOOP): the loop's accumulator type, conversion from / to the
 // group's reduced field, and this lane's limbs of an element.
+template <class K, bool PAIR>
+struct LazyPairNrm { using type = void; };
+template <class K>
+struct LazyPairNrm<K, true> { using type = typename K::template E<1, 2>; };
+
 template <class G>
 struct LazyOf {
     using F = typename G::F;
@@ -481,7 +487,9 @@ struct LazyOf {
     using AX = typename Acc::AX;
     using AY = typename Acc::AY;
     static constexpr int N = SPLIT ? LZ::N / 2 : LZ::N;                  // limbs held by one lane
-    PTAU_HD static AX to_lazy(const F &x) {
+    // a converted element (a product: limbs normalised, value below 2p), and a product of the group's field
+    using C = std::conditional_t<PAIR, typename LazyPairNrm<K, PAIR>::type, typename LZ::Nrm>;
+    PTAU_HD static C to_lazy(const F &x) {
         if constexpr (PAIR) return {LZ::from29(x.c)};
         else return LZ::from29(x);
     }
@@ -490,8 +498,9 @@ struct LazyOf {
         if constexpr (PAIR) return {LZ::to29(v.c)};
         else return LZ::to29(v);
     }
-    PTAU_HD static AX load(const uint32_t *w) {
-        AX r;
+    template <class T>
+    PTAU_HD static T load(const uint32_t *w) {   // this lane's N limbs of one coordinate
+        T r;
 #pragma unroll
         for (int j = 0; j < N; j++) {
             if constexpr (PAIR) r.c.l[j] = w[j];
@@ -499,19 +508,31 @@ struct LazyOf {
         }
         return r;
     }
-    PTAU_HD static void store(uint32_t *w, const AX &v) {
+    template <class T>
+    PTAU_HD static void store(uint32_t *w, const T &v) {
 #pragma unroll
         for (int j = 0; j < N; j++) {
             if constexpr (PAIR) w[j] = v.c.l[j];
             else w[j] = v.l[j];
         }
     }
+    PTAU_HD static void store_zero(uint32_t *w) {
+#pragma unroll
+        for (int j = 0; j < N; j++) w[j] = 0;
+    }
 };
 
 template <class G, bool LAZY>
-struct LoopAcc { using type = typename G::J; };
+struct LoopAcc {
+    using type = typename G::J;
+    using zc_type = char;   // unused
+};
 template <class G>
-struct LoopAcc<G, true> { using type = typename LazyOf<G>::Acc; };
+struct LoopAcc<G, true> {
+    using type = typename LazyOf<G>::Acc;
+    using L = LazyOf<G>;
+    using zc_type = decltype(L::K::mul(std::declval<typename L::C>(), std::declval<typename L::C>()));   // a product
+};
 
 template <class G>
 PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typename G::J *scratch,
@@ -533,26 +554,79 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
     }
     // table: e -> (e+1) * P   (lane-pair groups: one half-width Jacobian per lane, the pair adjacent)
     const uint64_t slot = i * G::LPP + (G::LPP == 2 ? lane_parity() : 0u), nslots = n * G::LPP;
-    J cur = J::from_affine(p);
-    wtab[slot] = cur;
     F zc = F::one();   // the table's common denominator (AFFINE_TABLE)
     using L = LazyOf<G>;                                   // named only: instantiated under LAZY_LOOP
     using AccT = typename LoopAcc<G, G::LAZY_LOOP>::type;   // the window loop's accumulator
-    // affine table entry e: (x, y) in the X and Y slots — or, for the carry-free loop, both converted, 2 x 14 limbs from the
-    // start of the entry's slot
-    auto put_entry = [&](int e, const F &x, const F &y) {
-        J *t = &wtab[(uint64_t)e * nslots + slot];
-        if constexpr (G::LAZY_LOOP) {
-            static_assert(sizeof(J) >= 2 * L::N * sizeof(uint32_t), "a converted entry must fit the Jacobian slot");
-            uint32_t *w = reinterpret_cast<uint32_t *>(t);
-            L::store(w, L::to_lazy(x));
-            L::store(w + L::N, L::to_lazy(y));
-        } else {
-            t->X = x;
-            t->Y = y;
+    typename LoopAcc<G, G::LAZY_LOOP>::zc_type zcz{};       // ... and the common denominator in its field
+    if constexpr (G::LAZY_LOOP) {
+        // The whole table in the carry-free field: the point converted once, seven mixed additions, the running product of the
+        // Z's, then every entry rescaled to the common denominator as below (same construction, same exceptional cases).
+        // Entry e keeps X | Y as 2 x N limbs per lane from the start of its slot; the Z's stay in private memory.
+        using K = typename L::K;
+        using KM = typename LoopAcc<G, true>::zc_type;
+        static_assert(sizeof(J) >= 2 * L::N * sizeof(uint32_t), "a converted entry must fit the Jacobian slot");
+        auto slot_w = [&](int e) { return reinterpret_cast<uint32_t *>(&wtab[(uint64_t)e * nslots + slot]); };
+        const typename L::C px = L::to_lazy(p.x), py = L::to_lazy(p.y);
+        const typename L::AX pxa = px;
+        const typename L::AY pya = py;
+        AccT cur = {px, py, K::one()};
+        decltype(cur.Zc) zs[WINDOW_ENTRIES - 1];
+        KM pre[WINDOW_ENTRIES - 1];
+        KM zl = K::one();
+#pragma nounroll
+        for (int e = 1; e < WINDOW_ENTRIES; e++) {
+            cur = AccT::add_mixed(cur, pxa, pya);
+            uint32_t *w = slot_w(e);
+            L::store(w, cur.X);
+            L::store(w + L::N, cur.Y);
+            zs[e - 1] = cur.Zc;
+            pre[e - 1] = zl;
+            if (!K::is_zero(cur.Zc)) zl = K::mul(zl, cur.Zc);
         }
+        // Fq2: a REAL common denominator Zc conj(Zc), so that psi keeps entries on it (see below)
+        auto suf = [&] {
+            if constexpr (L::PAIR) return K::conj(zl);
+            else return KM(K::one());
+        }();
+#pragma nounroll
+        for (int e = WINDOW_ENTRIES - 1; e >= 1; e--) {
+            uint32_t *w = slot_w(e);
+            const auto ze = zs[e - 1];
+            if (K::is_zero(ze)) {   // the multiple is O: (0, 0) marks it
+                L::store_zero(w);
+                L::store_zero(w + L::N);
+            } else {
+                const KM c = K::mul(pre[e - 1], suf);
+                suf = K::mul(suf, ze);
+                const auto c2 = K::sqr(c);
+                const KM x = K::mul(L::template load<decltype(cur.X)>(w), c2);
+                const KM y = K::mul(L::template load<decltype(cur.Y)>(w + L::N), K::mul(c2, c));
+                L::store(w, x);
+                L::store(w + L::N, y);
+            }
+        }
+        {   // entry 0 = P itself (Z = 1): c = Zc
+            if constexpr (L::PAIR) zcz = K::mul(zl, K::conj(zl));
+            else zcz = zl;
+            const auto c2 = K::sqr(zcz);
+            uint32_t *w = slot_w(0);
+            L::store(w, KM(K::mul(px, c2)));
+            L::store(w + L::N, KM(K::mul(py, K::mul(c2, zcz))));
+        }
+    }
+    J cur = J::infinity();
+    if constexpr (!G::LAZY_LOOP) {
+        cur = J::from_affine(p);
+        wtab[slot] = cur;
+    }
+    auto put_entry = [&](int e, const F &x, const F &y) {   // affine table entry e: (x, y) in the X and Y slots
+        J *t = &wtab[(uint64_t)e * nslots + slot];
+        t->X = x;
+        t->Y = y;
     };
-    if constexpr (G::AFFINE_TABLE) {
+    if constexpr (G::LAZY_LOOP) {
+        // table built above
+    } else if constexpr (G::AFFINE_TABLE) {
         // Jacobian multiples first, the running product of their Z's on the side; then, last to first, entry e is scaled by
         // c_e = Zc / Z_e = (product of the Z's before it) * (product of those after it): (X c^2, Y c^3) written to its X and
         // Y slots.  (0, 0), which is on no curve with b != 0, marks the point at infinity — a multiple of a small-order
@@ -600,8 +674,9 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
         if constexpr (G::LAZY_LOOP) {
             using K = typename L::K;
             const uint32_t *w = reinterpret_cast<const uint32_t *>(&wtab[(uint64_t)(mag - 1) * nslots + slot]);
-            auto x = L::load(w);
-            const auto y = L::load(w + L::N);
+            using KM = typename LoopAcc<G, true>::zc_type;
+            typename L::AX x = L::template load<KM>(w);
+            const KM y = L::template load<KM>(w + L::N);
             if (K::limbs_all_zero(x) && K::limbs_all_zero(y)) return;   // the multiple is O
             if constexpr (!L::PAIR) {
                 if (endo) x = K::mul(x, beta);
@@ -628,7 +703,7 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
     // leaving the loop: back from the isomorphic curve (Z Zc) and, for the carry-free accumulator, back to the reduced field
     auto finish = [&](const AccT &acc) -> J {
         if constexpr (G::LAZY_LOOP) {
-            const auto z = L::K::mul(acc.Zc, L::to_lazy(zc));
+            const auto z = L::K::mul(acc.Zc, zcz);
             return {L::from_lazy(acc.X), L::from_lazy(acc.Y), L::from_lazy(z)};
         } else {
             J r = acc;
@@ -734,13 +809,14 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
                         if constexpr (G::LAZY_LOOP) {
                             using K = typename L::K;
                             const uint32_t *tw = reinterpret_cast<const uint32_t *>(&wtab[(uint64_t)(mag - 1) * nslots + slot]);
-                            auto x = L::load(tw), y = L::load(tw + L::N);
+                            using KM = typename LoopAcc<G, true>::zc_type;
+                            KM x = L::template load<KM>(tw), y = L::template load<KM>(tw + L::N);
                             if (!(K::limbs_all_zero(x) && K::limbs_all_zero(y))) {
                                 if (h) {   // psi^h of the entry: conjugate for odd h, then one Fq constant per coordinate
                                     typename L::LZ::template E<1, 1> cx, cy;
 #pragma unroll
                                     for (int j = 0; j < L::N; j++) { cx.l[j] = Cfg::GLS_CZ[2 * (h - 1)][j]; cy.l[j] = Cfg::GLS_CZ[2 * (h - 1) + 1][j]; }
-                                    typename K::template E<3, 3> xc = x, yc = y;
+                                    decltype(K::conj(x)) xc = x, yc = y;
                                     if (h & 1) {
                                         xc = K::conj(x);
                                         yc = K::conj(y);
