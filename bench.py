@@ -252,20 +252,22 @@ def macs_per_update(curve, group, endo):
     rescale = 51 * m if a_zero else 0
     bits = SCALAR_BITS[curve]
     if curve == "bls12_377":
-        # the window loop runs in the carry-free twin field (fpz.hpp): 14 limbs of 28 bits; mixed addition 8M + 3S
-        # (Z3 = 2 Z1 H); 16 + 1 + 3 converting products (table entries, Zc, result), one more for beta
+        # table and window loop run in the carry-free twin field (fpz.hpp): 14 limbs of 28 bits; mixed addition 8M + 3S
+        # (Z3 = 2 Z1 H); one more converting product for beta
         mz, sqz = 2 * 14 * 14, 14 * 14 + 14 * 15 // 2
         dblz, maddz = 2 * mz + 5 * sqz, 8 * mz + 3 * sqz
-        table = 7 * madd + rescale + 20 * mz
+        # table in the same field: 7 mixed additions, 7 + 7 * 5 + 3 products and 8 squares for the common denominator,
+        # 2 + 3 converting products (the point in, the result out)
+        table = 7 * maddz + 50 * mz + 8 * sqz
         if endo:
             return (4 * 32 - 4) * dblz + 2 * 32 * 15 // 16 * maddz + 32 * 15 // 16 * mz + mz + table
         windows = (bits + 3 + 3) // 4
         return (4 * windows - 4) * dblz + windows * 15 // 16 * maddz + table
     if curve == "bw6":
-        # the window loop runs in the carry-free lane-split field (fplz.hpp): the same 28 limbs; mixed addition 8M + 3S;
-        # 16 + 1 + 3 converting products, one more for beta
+        # table and window loop run in the carry-free lane-split field (fplz.hpp): the same 28 limbs; mixed addition 8M + 3S;
+        # one more converting product for beta
         maddz = 8 * m + 3 * sq
-        table = 7 * madd + rescale + 20 * m
+        table = 7 * maddz + 50 * m + 8 * sq
         if endo:
             return (4 * 48 - 4) * dbl + 2 * 48 * 15 // 16 * maddz + 48 * 15 // 16 * m + m + table
         windows = (bits + 3 + 3) // 4
