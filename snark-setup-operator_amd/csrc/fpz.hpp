@@ -17,8 +17,9 @@
 // U 2^28, value below V p"; each operation computes the bounds of its result and static_asserts what it needs
 // (product: U1 U2 <= 16 keeps a column sum below 2^64; V1 V2 <= 2^15 keeps the result below 2p).
 // Same Montgomery residue as Fp29 up to the constant factor R / R29: from29 / to29 convert by one product.
-// Used only between the window table and the result store of window_scalar_mul_kernel (kernels_impl.hpp, LAZY_LOOP); the
-// reference path it serves is batch_exp, /root/reference/src/bin/contribute.rs:811-823.
+// Used between the point read and the result store of window_scalar_mul_kernel (table and window loop), by the phi / psi
+// membership kernels and by the G2 bucket accumulation (kernels_impl.hpp, LAZY_LOOP); the reference paths they serve are
+// batch_exp, check_subgroup and dense_multiexp — /root/reference/src/bin/contribute.rs:811-823, 140-145, 968-986.
 #pragma once
 #include "fp29.hpp"
 #include "fpl.hpp"   // lane_parity / lane_xchg / lane_bcast_*

@@ -97,7 +97,7 @@ struct GroupTypes {
 #endif
     static constexpr bool AFFINE_TABLE = PTAU_AFFINE_TABLE && Cfg::A_IS_ZERO && F::DEG <= 2 && F::POINT_OPS_INLINE;
     // K1's window loop in the carry-free twin of the base field (fpz.hpp): BLS12-377 G1, and G2 with Fq2 over a lane pair.
-    // The table is built as before and converted entry by entry; the accumulator is converted back before the result store.
+    // The point is converted once, table and loop run there, the accumulator is converted back before the result store.
 #ifndef PTAU_LAZY_LOOP
 #define PTAU_LAZY_LOOP 1
 #endif
