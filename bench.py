@@ -119,7 +119,7 @@ def whole_chunk_extras(pkg, curve, power, log2n, dev):
     d = tempfile.mkdtemp(prefix="ptau_bench_", dir=base)
     f = lambda name: os.path.join(d, name)
     elems = n1 + 3 * n2 + 1
-    out = {"host_blake2b": {0: "portable", 1: "avx2"}[pkg.load_library().ptau_blake2b_implementation(-1)],
+    out = {"host_blake2b": (lambda v: {0: "portable", 1: "avx2", 2: "bmi2", 3: "avx512"}.get(v, str(v)))(pkg.load_library().ptau_blake2b_implementation(-1)),
            "workload": "%s power %d chunk 0, chunk_size 2^%d: %d G1 + %d G2 elements; challenge %d B, response %d B; "
                        "file-level entry points, files on %s" % (curve, power, log2n, n1 + 2 * n2, n2 + 1, prm.accumulator_size,
                                                                   prm.contribution_size, base or "the default tmp dir")}
@@ -305,6 +305,83 @@ def golden_generator(curve, group):
     return chal, n1
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def rank_env(rank, world, port, base_env=None):
+    """Environment of rank `rank` of a `world`-rank job on this node (what torchrun would export)."""
+    env = dict(os.environ if base_env is None else base_env)
+    env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
+                "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                "PTAU_BENCH_CHILD": "1"})
+    return env
+
+
+def launch_ranks(world, argv, script=None, popen=None, timeout=None):
+    """`python bench.py --gpus N` without torchrun: the parent — which has imported neither torch nor the HIP library, so no
+    process that initialised the GPU ever forks or execs — starts one child per GPU with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set, relays rank 0's stdout (the ONE JSON line) and every rank's stderr, and exits non-zero if any rank failed
+    (the survivors are terminated: a dead rank would leave them in the barrier)."""
+    import subprocess
+    popen = popen or subprocess.Popen
+    script = script or os.path.abspath(__file__)
+    port = free_port()
+    procs = []
+    for r in range(world):
+        procs.append(popen([sys.executable, script] + list(argv), env=rank_env(r, world, port),
+                           stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None))
+    deadline = time.time() + timeout if timeout else None
+    rc = 0
+    out0 = b""
+    pending = set(range(world))
+    try:
+        while pending:
+            for r in sorted(pending):
+                p = procs[r]
+                if r == 0 and p.stdout is not None:
+                    try:
+                        o, _ = p.communicate(timeout=0.5)
+                        out0 += o or b""
+                    except subprocess.TimeoutExpired:
+                        pass
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    sys.stderr.write("bench.py: rank %d exited with code %d\n" % (r, code))
+            if rc or (deadline and time.time() > deadline):
+                if not rc:
+                    rc = 124
+                    sys.stderr.write("bench.py: ranks timed out\n")
+                break
+            if pending and 0 not in pending:
+                time.sleep(0.2)
+    finally:
+        for r in pending:
+            try:
+                procs[r].terminate()
+            except Exception:
+                pass
+        for r in pending:
+            try:
+                procs[r].wait(timeout=20)
+            except Exception:
+                try:
+                    procs[r].kill()
+                except Exception:
+                    pass
+    if out0:
+        sys.stdout.write(out0.decode(errors="replace"))
+        sys.stdout.flush()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -321,10 +398,17 @@ def main():
                          "the one `value` and `roofline` describe, so the profile's per-kernel averages are comparable to them")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` with no launcher around it: start the N ranks here, before torch or HIP are touched
+    # (under torchrun / as a child RANK is set and this process IS a rank)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(1, args.gpus) and rank == 0:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: the launcher's world size is used\n" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     # rehearsal knobs for a one-GPU box (the driver's N > 1 runs use neither): PTAU_BENCH_BACKEND=gloo lets several ranks
@@ -332,6 +416,9 @@ def main():
     backend = os.environ.get("PTAU_BENCH_BACKEND", "nccl")
     if "PTAU_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["PTAU_BENCH_DEVICE"])
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d needs GPU %d but this node has %d (one rank per GPU; PTAU_BENCH_BACKEND=gloo "
+                         "PTAU_BENCH_DEVICE=0 rehearses N ranks on one device)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -505,6 +592,50 @@ def main():
         dist.destroy_process_group()
 
 
+def sharded_ratios_line(args, pkg, dev, rank, world, dist, f, prm, lg, barrier):
+    """The one exchange step of the path, executed over the job's process group: the whole-transcript ratio
+    check of verify_transcript (phase1_cli::transform_ratios, control.rs:587-591) with every vector's power_pairs reduction
+    sliced over the ranks and ONE all_gather of the partial pairs per vector — RCCL over xGMI when the backend is nccl.
+    Rank 0 builds the combined accumulator of the round (chunk 0 + the tauG1-only chunk 1 -> combine, untimed) in a
+    directory every rank of the node can map; all ranks then run the sharded check on it."""
+    import mmap
+    import shutil
+    n = 1 << lg
+    shared = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp",
+                          "ptau_bench_combined_%s" % os.environ.get("MASTER_PORT", str(os.getpid())))
+    full = pkg.Phase1Parameters.new_full("bls12_377", 0, lg, n)
+    try:
+        if rank == 0:
+            os.makedirs(shared, exist_ok=True)
+            prm1 = pkg.Phase1Parameters.new_chunk("bls12_377", 0, 1, n, 0, lg, n)
+            pkg.new_challenge(f("d0"), f("d0.hash"), prm1)
+            pkg.phase1_cli.contribute_seeded(f("d0"), f("d0.h2"), f("s0"), f("s0.hash"), pkg.CheckForCorrectness.No, pkg.BatchExpMode.Auto,
+                                             prm1, b"bench verify seed".ljust(64, b"."), device=dev)
+            open(os.path.join(shared, "list"), "w").write(f("r0") + "\n" + f("s0") + "\n")
+            pkg.phase1_cli.combine_file(os.path.join(shared, "list"), os.path.join(shared, "combined"), prm, device=dev)
+        barrier()
+        with open(os.path.join(shared, "combined"), "rb") as fh:
+            mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+            try:
+                pkg.phase1_cli.transform_ratios_sharded(mm, full, dist=dist, device=dev)      # warm-up (workspace growth)
+                barrier()
+                t0 = time.perf_counter()
+                pkg.phase1_cli.transform_ratios_sharded(mm, full, dist=dist, device=dev)
+                barrier()
+                dt = time.perf_counter() - t0
+            finally:
+                mm.close()
+        return {"seconds": dt, "ranks": world, "backend": (dist.get_backend() if dist is not None else "none"),
+                "combined_bytes": full.accumulator_size,
+                "what": "transform_ratios on the 2^%d combined accumulator: tauG1 (2^%d - 1), tauG2, alphaG1, betaG1 sliced over the "
+                        "ranks (one rho stream keyed by the global index), one all_gather of the partial pairs per vector, 5 "
+                        "pairing checks" % (lg, lg + 1)}
+    finally:
+        barrier()
+        if rank == 0:
+            shutil.rmtree(shared, ignore_errors=True)
+
+
 def bench_verify(args, pkg, dev, rank, world, dist, backend, barrier):
     """--config 5: verification of one 2^20 BLS12-377 chunk per GPU (BASELINE configs[4], second half of the metric).  A step =
     phase1_cli::transform_pok_and_correctness on chunk 0 (files on tmpfs, ratio check on): the boundary of this path is the
@@ -545,6 +676,7 @@ def bench_verify(args, pkg, dev, rank, world, dist, backend, barrier):
             tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
+        sharded = sharded_ratios_line(args, pkg, dev, rank, world, dist, f, prm, lg, barrier)
         if rank == 0:
             assert open(f("c1"), "rb").read(64) == open(f("v.r.hash"), "rb").read()
             elems = 4 * n + 1
@@ -563,6 +695,7 @@ def bench_verify(args, pkg, dev, rank, world, dist, backend, barrier):
                 "roofline": {"bound": "hbm", "kernel": "endo_subgroup_kernel (G1 x3 vectors + G2)", "kernel_ms": sub_ms / args.steps,
                              "achieved": algo / sub_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo / sub_s / 1e9 / HBM_PEAK_GBS,
                              "traffic": None, "note": "membership tests are ~126 doublings per element: integer-ALU-bound, see DESIGN.md"},
+                "sharded_transform_ratios": sharded,
                 "cpu_baseline": None}))
     finally:
         shutil.rmtree(d, ignore_errors=True)

@@ -96,6 +96,10 @@ typedef struct ptau_timing {
     double scalar_mul_ms, normalize_ms; /* the two kernels of the tau-update */
     uint64_t points;                  /* group elements processed */
     double decompress_ms, subgroup_ms, msm_ms; /* verify path: sqrt, subgroup checks, bucket MSMs (parts of kernel_ms) */
+    /* verification calls: how many same-ratio (pairing) checks the call ran — power-ratio checks of check_power_ratios and
+     * proofs of knowledge / chunk-0 before-after checks.  ratio_checks == 0 after a call with ratio_check != 0 means "NOT
+     * PERFORMED": a chunk without tauG2 elements and no tau_g2_check (see ptau_verify_chunk). */
+    uint32_t ratio_checks, pok_checks;
 } ptau_timing;
 
 const char *ptau_strerror(int code);
@@ -187,13 +191,17 @@ int ptau_verify_chunk(const ptau_params *p, const uint8_t *challenge, size_t cha
  * before/after checks (always), element checks, ratio checks, decompression; writes the three 64-byte `.hash` side files
  * and creates new_challenge_path (create_new semantics).  g2_s: NULL (derived by the library, as the reference does) or
  * the three compute_g2_s points computed by the Rust host (uncompressed), which removes the one step whose bit-exactness
- * with arkworks cannot be pinned offline (ptau_compute_g2_s). */
+ * with arkworks cannot be pinned offline (ptau_compute_g2_s).
+ * tau_g2_check: NULL, or the two UNCOMPRESSED G2 points (tauG2[0], tauG2[1]) of the same contribution (the head of the
+ * chunk-0 new challenge): lets ratio_check cover a chunk that holds no tauG2 elements of its own (start >= 2^power).
+ * Without it such a chunk's tauG1 power ratios are NOT checked here (ptau_last_timing().ratio_checks == 0 says so) and
+ * are left to ptau_transform_ratios_file on the combined accumulator. */
 int ptau_transform_pok_and_correctness_file(const ptau_params *p, const char *challenge_path,
                                             const char *challenge_hash_path, int check_input, const char *response_path,
                                             const char *response_hash_path, int check_output,
                                             const char *new_challenge_path, const char *new_challenge_hash_path,
                                             int subgroup_check_mode, int ratio_check, const uint8_t *g2_s,
-                                            int device, char *err, size_t err_len);
+                                            const uint8_t *tau_g2_check, int device, char *err, size_t err_len);
 
 /* setup_utils::dense_multiexp — sum_i scalars[i] * in[i] -> one serialized point (host buffers; scalars are
  * n x ptau_fr_limbs(curve) canonical limbs).  Used inside merge_pairs / power_pairs. */
@@ -253,6 +261,35 @@ int ptau_combine(const ptau_params *full, uint64_t chunk_size, const uint8_t *co
  * the betaG2 consistency check on a combined accumulator.  -> PTAU_E_INVALID_RATIO */
 int ptau_transform_ratios(const ptau_params *full, const uint8_t *combined, size_t combined_len, int check_input,
                           int device, char *err, size_t err_len);
+
+/* phase1_cli::combine(response_list_filename, combined_filename, &parameters) in the reference's FILE form and argument
+ * order (src/bin/control.rs:564-568, src/bin/verify_transcript.rs:603-607): `chunk0` = the parameters of chunk 0
+ * (create_parameters_for_chunk(.., 0): curve, power, chunk_size, batch_size); response_list_path = a text file with one
+ * chunk-response path per line, in chunk order (control.rs:547-557 writes it); combined_path is CREATED (create_new
+ * semantics — the caller removes a stale one first, control.rs:560) with the Full-mode accumulator_size and filled with
+ * the decompressed vectors.  Its first 64 bytes stay zero: the reference creates the file with set_len and
+ * Phase1::aggregation writes the element vectors only (recollection of phase1-cli/src/combine.rs @ bd530da — UNPINNED;
+ * BLAKE2b(combined) is what the beacon contribution that follows puts in its response header, verify_transcript.rs:675-696).
+ * The responses are mapped, never read into the heap. */
+int ptau_combine_file(const ptau_params *chunk0, const char *response_list_path, const char *combined_path, int device,
+                      char *err, size_t err_len);
+
+/* phase1_cli::transform_ratios(combined_filename, check_input_correctness, &full_parameters), file form
+ * (src/bin/control.rs:587-591, src/bin/verify_transcript.rs:646-653, 811-822): the file is mapped read-only (it may be a
+ * `combined` file or the new challenge of the beacon verification — both are Full-mode accumulators).  */
+int ptau_transform_ratios_file(const ptau_params *full, const char *combined_path, int check_input, int device, char *err,
+                               size_t err_len);
+
+/* The same check spread over SEVERAL devices from ONE process (the operator is one process with lane threads,
+ * src/bin/contribute.rs:467-492): every vector's pair indices are cut into n_devices contiguous slices
+ * (overlapping by one element), slice k is reduced by power_pairs on devices[k] on its own host thread under ONE rho stream
+ * (one seed, coefficients keyed by the global index), the n_devices partial pairs per vector are summed and the five
+ * pairing checks run once, on devices[0].  Same accept / reject set as ptau_transform_ratios.  check_input: each slice is
+ * membership-tested on its device. */
+int ptau_transform_ratios_devices(const ptau_params *full, const uint8_t *combined, size_t combined_len, int check_input,
+                                  const int *devices, int n_devices, char *err, size_t err_len);
+int ptau_transform_ratios_file_devices(const ptau_params *full, const char *combined_path, int check_input,
+                                       const int *devices, int n_devices, char *err, size_t err_len);
 
 /* Phase1::verification steps (1)-(2) (inside transform_pok_and_correctness, src/bin/contribute.rs:968-986):
  * the three proofs of knowledge in the PublicKey at the tail of `response`, and for chunk 0 / Full mode the

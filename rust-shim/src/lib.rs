@@ -58,6 +58,8 @@ pub struct PtauTiming {
     pub decompress_ms: f64,
     pub subgroup_ms: f64,
     pub msm_ms: f64,
+    pub ratio_checks: u32,
+    pub pok_checks: u32,
 }
 
 pub const PTAU_BATCH_EXP_INPUT_IN_SUBGROUP: c_int = 0x100;
@@ -74,11 +76,15 @@ extern "C" {
     pub fn ptau_phase1_computation(p: *const PtauParams, input: *const u8, in_len: usize, output: *mut u8, out_len: usize, tau: *const u64, alpha: *const u64, beta: *const u64, check_input: c_int, batch_exp_mode: c_int, device: c_int, err: *mut c_char, err_len: usize) -> c_int;
     pub fn ptau_contribute_file(p: *const PtauParams, challenge_path: *const c_char, challenge_hash_path: *const c_char, response_path: *const c_char, response_hash_path: *const c_char, tau: *const u64, alpha: *const u64, beta: *const u64, public_key: *const u8, public_key_len: usize, check_input: c_int, batch_exp_mode: c_int, device: c_int, err: *mut c_char, err_len: usize) -> c_int;
     pub fn ptau_contribute_file_seeded(p: *const PtauParams, challenge_path: *const c_char, challenge_hash_path: *const c_char, response_path: *const c_char, response_hash_path: *const c_char, seed: *const u8, seed_len: usize, check_input: c_int, batch_exp_mode: c_int, device: c_int, err: *mut c_char, err_len: usize) -> c_int;
-    pub fn ptau_transform_pok_and_correctness_file(p: *const PtauParams, challenge_path: *const c_char, challenge_hash_path: *const c_char, check_input: c_int, response_path: *const c_char, response_hash_path: *const c_char, check_output: c_int, new_challenge_path: *const c_char, new_challenge_hash_path: *const c_char, subgroup_check_mode: c_int, ratio_check: c_int, g2_s: *const u8, device: c_int, err: *mut c_char, err_len: usize) -> c_int;
+    pub fn ptau_transform_pok_and_correctness_file(p: *const PtauParams, challenge_path: *const c_char, challenge_hash_path: *const c_char, check_input: c_int, response_path: *const c_char, response_hash_path: *const c_char, check_output: c_int, new_challenge_path: *const c_char, new_challenge_hash_path: *const c_char, subgroup_check_mode: c_int, ratio_check: c_int, g2_s: *const u8, tau_g2_check: *const u8, device: c_int, err: *mut c_char, err_len: usize) -> c_int;
     pub fn ptau_new_challenge_file(p: *const PtauParams, challenge_path: *const c_char, challenge_hash_path: *const c_char, err: *mut c_char, err_len: usize) -> c_int;
     pub fn ptau_new_challenge_with_generators(p: *const PtauParams, g1_generator: *const u8, g2_generator: *const u8, out: *mut u8, out_len: usize, err: *mut c_char, err_len: usize) -> c_int;
     pub fn ptau_combine(full: *const PtauParams, chunk_size: u64, responses: *const *const u8, response_lens: *const usize, n_chunks: u64, combined: *mut u8, combined_len: usize, device: c_int, err: *mut c_char, err_len: usize) -> c_int;
     pub fn ptau_transform_ratios(full: *const PtauParams, combined: *const u8, combined_len: usize, check_input: c_int, device: c_int, err: *mut c_char, err_len: usize) -> c_int;
+    pub fn ptau_combine_file(chunk0: *const PtauParams, response_list_path: *const c_char, combined_path: *const c_char, device: c_int, err: *mut c_char, err_len: usize) -> c_int;
+    pub fn ptau_transform_ratios_file(full: *const PtauParams, combined_path: *const c_char, check_input: c_int, device: c_int, err: *mut c_char, err_len: usize) -> c_int;
+    pub fn ptau_transform_ratios_devices(full: *const PtauParams, combined: *const u8, combined_len: usize, check_input: c_int, devices: *const c_int, n_devices: c_int, err: *mut c_char, err_len: usize) -> c_int;
+    pub fn ptau_transform_ratios_file_devices(full: *const PtauParams, combined_path: *const c_char, check_input: c_int, devices: *const c_int, n_devices: c_int, err: *mut c_char, err_len: usize) -> c_int;
     pub fn ptau_key_generation(curve: c_int, seed: *const u8, seed_len: usize, digest: *const u8, tau: *mut u64, alpha: *mut u64, beta: *mut u64, public_key: *mut u8, public_key_len: usize, err: *mut c_char, err_len: usize) -> c_int;
     pub fn ptau_compute_g2_s(curve: c_int, digest: *const u8, public_key: *const u8, public_key_len: usize, g2_s_out: *mut u8, err: *mut c_char, err_len: usize) -> c_int;
     pub fn ptau_last_timing(device: c_int, out: *mut PtauTiming) -> c_int;
@@ -169,17 +175,19 @@ pub mod phase1_cli {
     }
 
     /// `phase1_cli::transform_pok_and_correctness` (`contribute.rs:968-986`), the reference's eleven arguments; `g2_s`:
-    /// `None` (derived by the library) or arkworks' three `compute_g2_s` points, uncompressed.
+    /// `None` (derived by the library) or arkworks' three `compute_g2_s` points, uncompressed; `tau_g2_check`: `None`, or
+    /// `tauG2[0] | tauG2[1]` (uncompressed) of the same contribution so that `ratio_check` covers a tauG1-only chunk.
     pub fn transform_pok_and_correctness(challenge_filename: &str, challenge_hash_filename: &str, check_input_correctness: CheckForCorrectness,
                                          response_filename: &str, response_hash_filename: &str, check_output_correctness: CheckForCorrectness,
                                          new_challenge_filename: &str, new_challenge_hash_filename: &str, subgroup_check_mode: SubgroupCheckMode,
-                                         ratio_check: bool, parameters: &PtauParams, g2_s: Option<&[u8]>, device: i32) {
+                                         ratio_check: bool, parameters: &PtauParams, g2_s: Option<&[u8]>, tau_g2_check: Option<&[u8]>, device: i32) {
         let mut err = [0 as c_char; 256];
         let (c, ch, r, rh, n, nh) = (cpath(challenge_filename), cpath(challenge_hash_filename), cpath(response_filename),
                                      cpath(response_hash_filename), cpath(new_challenge_filename), cpath(new_challenge_hash_filename));
         let rc = unsafe { ptau_transform_pok_and_correctness_file(parameters, c.as_ptr(), ch.as_ptr(), check_input_correctness as c_int, r.as_ptr(), rh.as_ptr(),
                                                                   check_output_correctness as c_int, n.as_ptr(), nh.as_ptr(), subgroup_check_mode as c_int,
-                                                                  ratio_check as c_int, g2_s.map_or(std::ptr::null(), |s| s.as_ptr()), device,
+                                                                  ratio_check as c_int, g2_s.map_or(std::ptr::null(), |s| s.as_ptr()),
+                                                                  tau_g2_check.map_or(std::ptr::null(), |s| s.as_ptr()), device,
                                                                   err.as_mut_ptr(), err.len()) };
         check("phase1_cli::transform_pok_and_correctness", rc, &err);
     }
@@ -205,8 +213,29 @@ pub mod phase1_cli {
         out
     }
 
-    /// `phase1_cli::combine` (`control.rs:564-568`, `verify_transcript.rs:603-607`) on in-memory responses.
-    pub fn combine(responses: &[&[u8]], chunk_size: usize, full_parameters: &PtauParams, device: i32) -> Vec<u8> {
+    /// `phase1_cli::combine(response_list_filename, combined_filename, &parameters)` (`control.rs:564-568`,
+    /// `verify_transcript.rs:603-607`) — the reference's three arguments: `parameters` = `create_parameters_for_chunk(.., 0)`;
+    /// the library maps the listed responses and CREATES `combined_filename` (nothing passes through the Rust heap).
+    pub fn combine(response_list_filename: &str, combined_filename: &str, parameters: &PtauParams, device: i32) {
+        let mut err = [0 as c_char; 256];
+        let (l, c) = (cpath(response_list_filename), cpath(combined_filename));
+        let rc = unsafe { ptau_combine_file(parameters, l.as_ptr(), c.as_ptr(), device, err.as_mut_ptr(), err.len()) };
+        check("phase1_cli::combine", rc, &err);
+    }
+
+    /// `phase1_cli::transform_ratios(combined_filename, check_input_correctness, &full_parameters)` (`control.rs:587-591`,
+    /// `verify_transcript.rs:646-653, 811-822`).  `devices`: one ordinal, or several — the operator is ONE process, so the
+    /// final ratio check reaches the node's GPUs through host threads inside the library (`ptau_transform_ratios_file_devices`).
+    pub fn transform_ratios(combined_filename: &str, check_input_correctness: CheckForCorrectness, full_parameters: &PtauParams, devices: &[i32]) {
+        let mut err = [0 as c_char; 256];
+        let c = cpath(combined_filename);
+        let rc = unsafe { ptau_transform_ratios_file_devices(full_parameters, c.as_ptr(), check_input_correctness as c_int, devices.as_ptr(),
+                                                             devices.len() as c_int, err.as_mut_ptr(), err.len()) };
+        check("phase1_cli::transform_ratios", rc, &err);
+    }
+
+    /// Buffer-level forms (tests, hosts that already hold the accumulator in memory).
+    pub fn combine_buffers(responses: &[&[u8]], chunk_size: usize, full_parameters: &PtauParams, device: i32) -> Vec<u8> {
         let mut sz = PtauSizes::default();
         assert_eq!(unsafe { ptau_params_sizes(full_parameters, &mut sz) }, 0, "invalid parameters");
         let ptrs: Vec<*const u8> = responses.iter().map(|r| r.as_ptr()).collect();
@@ -218,15 +247,16 @@ pub mod phase1_cli {
         check("phase1_cli::combine", rc, &err);
         out
     }
-
-    /// `phase1_cli::transform_ratios` (`control.rs:587-591`, `verify_transcript.rs:646-653, 812-822`).
-    pub fn transform_ratios(combined: &[u8], check_input_correctness: CheckForCorrectness, full_parameters: &PtauParams, device: i32) {
+    pub fn transform_ratios_buffer(combined: &[u8], check_input_correctness: CheckForCorrectness, full_parameters: &PtauParams, devices: &[i32]) {
         let mut err = [0 as c_char; 256];
-        let rc = unsafe { ptau_transform_ratios(full_parameters, combined.as_ptr(), combined.len(), check_input_correctness as c_int, device,
-                                                err.as_mut_ptr(), err.len()) };
+        let rc = unsafe { ptau_transform_ratios_devices(full_parameters, combined.as_ptr(), combined.len(), check_input_correctness as c_int,
+                                                        devices.as_ptr(), devices.len() as c_int, err.as_mut_ptr(), err.len()) };
         check("phase1_cli::transform_ratios", rc, &err);
     }
 }
+
+/// Every usable device ordinal: what `transform_ratios` takes when the whole node serves the final check.
+pub fn all_devices() -> Vec<i32> { (0..unsafe { ptau_device_count() }).collect() }
 
 /// `processor_data` for `ContributedData` (`contribute.rs:858-864`): the GPU that did the work.
 pub fn processor_name(device: i32) -> String {

@@ -23,6 +23,7 @@ DECLARED_SYMBOLS = [
     "ptau_combine", "ptau_transform_ratios", "ptau_verify_pok", "ptau_new_challenge_with_generators", "ptau_generator",
     "ptau_chacha20_rng_words", "ptau_key_generation", "ptau_private_key_from_seed", "ptau_compute_g2_s", "ptau_contribute_file_seeded",
     "ptau_check_same_ratio_batch", "ptau_blake2b_implementation", "ptau_device_busy_ms",
+    "ptau_combine_file", "ptau_transform_ratios_file", "ptau_transform_ratios_devices", "ptau_transform_ratios_file_devices",
 ]
 
 
@@ -49,7 +50,8 @@ class ptau_sizes(ctypes.Structure):
 class ptau_timing(ctypes.Structure):
     _fields_ = [("h2d_ms", ctypes.c_double), ("kernel_ms", ctypes.c_double), ("d2h_ms", ctypes.c_double),
                 ("scalar_mul_ms", ctypes.c_double), ("normalize_ms", ctypes.c_double), ("points", ctypes.c_uint64),
-                ("decompress_ms", ctypes.c_double), ("subgroup_ms", ctypes.c_double), ("msm_ms", ctypes.c_double)]
+                ("decompress_ms", ctypes.c_double), ("subgroup_ms", ctypes.c_double), ("msm_ms", ctypes.c_double),
+                ("ratio_checks", ctypes.c_uint32), ("pok_checks", ctypes.c_uint32)]
 
 
 def load_library():
@@ -86,7 +88,11 @@ def load_library():
     L.ptau_verify_pok.argtypes = [ctypes.POINTER(ptau_params), u8p, sz, u8p, sz, u8p, cp, sz]
     L.ptau_subgroup_check.argtypes = [i, i, u8p, i, u64, i, cp, sz]
     L.ptau_verify_chunk.argtypes = [ctypes.POINTER(ptau_params), u8p, sz, u8p, sz, u8p, sz, i, i, i, i, i, u8p, u8p, i, cp, sz]
-    L.ptau_transform_pok_and_correctness_file.argtypes = [ctypes.POINTER(ptau_params), cp, cp, i, cp, cp, i, cp, cp, i, i, u8p, i, cp, sz]
+    L.ptau_transform_pok_and_correctness_file.argtypes = [ctypes.POINTER(ptau_params), cp, cp, i, cp, cp, i, cp, cp, i, i, u8p, u8p, i, cp, sz]
+    L.ptau_combine_file.argtypes = [ctypes.POINTER(ptau_params), cp, cp, i, cp, sz]
+    L.ptau_transform_ratios_file.argtypes = [ctypes.POINTER(ptau_params), cp, i, i, cp, sz]
+    L.ptau_transform_ratios_devices.argtypes = [ctypes.POINTER(ptau_params), u8p, sz, i, ctypes.POINTER(ctypes.c_int), i, cp, sz]
+    L.ptau_transform_ratios_file_devices.argtypes = [ctypes.POINTER(ptau_params), cp, i, ctypes.POINTER(ctypes.c_int), i, cp, sz]
     L.ptau_new_challenge_with_generators.argtypes = [ctypes.POINTER(ptau_params), u8p, u8p, u8p, sz, cp, sz]
     L.ptau_generator.argtypes = [i, i, u8p, sz, cp, sz]
     L.ptau_chacha20_rng_words.argtypes = [u8p, u64, ctypes.POINTER(ctypes.c_uint32), sz]

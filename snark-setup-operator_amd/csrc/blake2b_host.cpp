@@ -4,6 +4,8 @@
 #include <immintrin.h>
 
 #include <algorithm>
+#include <atomic>
+#include <mutex>
 #include <chrono>
 #include <cstring>
 
@@ -148,7 +150,8 @@ __attribute__((target("avx512f,avx512vl,avx2"))) void compress_avx512(uint64_t h
 
 // Which form is faster depends on the core (measured: AVX2 +14 % on a 2.1 GHz Xeon, -38 % on an EPYC 9575F, whose scalar
 // pipes beat the vpinsrq-built message vectors), so the first use times every available form on 512 KB and keeps the winner.
-int g_impl = -1;
+std::atomic<int> g_impl{-1};
+std::once_flag g_pick_once;
 constexpr int N_IMPL = 4;
 inline void compress_with(int impl, uint64_t h[8], const uint8_t *blk, uint64_t t0, uint64_t t1, bool last) {
     if (impl == 3) compress_avx512(h, blk, t0, t1, last);
@@ -165,32 +168,39 @@ bool have_impl(int impl) {
     }
     return false;
 }
+// The timing race runs ONCE per process (std::call_once: the two hashing threads of a cold first verification start
+// together), on a local probe block; a forced choice made earlier (blake2b_implementation) is kept.
 int pick() {
-    if (g_impl >= 0) return g_impl;
-    static uint8_t probe[128];
-    double best[N_IMPL] = {1e30, 1e30, 1e30, 1e30};
-    for (int rep = 0; rep < 3; rep++)
-        for (int impl = 0; impl < N_IMPL; impl++) {
-            if (!have_impl(impl)) continue;
-            uint64_t hh[8];
-            memcpy(hh, IV, sizeof hh);
-            const auto t0 = std::chrono::steady_clock::now();
-            for (int i = 0; i < 4096; i++) compress_with(impl, hh, probe, 128ull * i, 0, false);
-            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            probe[rep] ^= (uint8_t)hh[0];   // keep the work observable
-            if (dt < best[impl]) best[impl] = dt;
-        }
-    g_impl = 0;
-    for (int impl = 1; impl < N_IMPL; impl++)
-        if (best[impl] < best[g_impl]) g_impl = impl;
-    return g_impl;
+    const int cur = g_impl.load(std::memory_order_acquire);
+    if (cur >= 0) return cur;
+    std::call_once(g_pick_once, [] {
+        if (g_impl.load(std::memory_order_acquire) >= 0) return;
+        uint8_t probe[128] = {0};
+        double best[N_IMPL] = {1e30, 1e30, 1e30, 1e30};
+        for (int rep = 0; rep < 3; rep++)
+            for (int impl = 0; impl < N_IMPL; impl++) {
+                if (!have_impl(impl)) continue;
+                uint64_t hh[8];
+                memcpy(hh, IV, sizeof hh);
+                const auto t0 = std::chrono::steady_clock::now();
+                for (int i = 0; i < 4096; i++) compress_with(impl, hh, probe, 128ull * i, 0, false);
+                const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                probe[rep] ^= (uint8_t)hh[0];   // keep the work observable
+                if (dt < best[impl]) best[impl] = dt;
+            }
+        int w = 0;
+        for (int impl = 1; impl < N_IMPL; impl++)
+            if (best[impl] < best[w]) w = impl;
+        g_impl.store(w, std::memory_order_release);
+    });
+    return g_impl.load(std::memory_order_acquire);
 }
 inline void compress(uint64_t h[8], const uint8_t *blk, uint64_t t0, uint64_t t1, bool last) { compress_with(pick(), h, blk, t0, t1, last); }
 
 }  // namespace
 
 int blake2b_implementation(int force) {
-    if (force >= 0 && force < N_IMPL && have_impl(force)) g_impl = force;
+    if (force >= 0 && force < N_IMPL && have_impl(force)) g_impl.store(force, std::memory_order_release);
     return pick();
 }
 

@@ -16,8 +16,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <array>
 #include <atomic>
 #include <future>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -27,6 +29,10 @@
 #include "kernels_impl.hpp"
 #include "pairing_dev.hpp"
 #include "pairing_host.hpp"
+
+namespace ptau {
+int host_validate_points(int curve, int group, const uint8_t *pts, size_t n);   // keygen.hip
+}
 
 namespace {
 
@@ -235,8 +241,13 @@ int run_apply_powers_dev(DeviceCtx *c, int curve, int group, const GroupOps *ops
     if (use_endo == 2) {   // Auto, membership unknown: probe where the test is cheap next to the saving
         use_endo = 0;
         if (ops->membership_cheap && n) {
-            Err quiet{nullptr, 0};
-            if (run_subgroup_check_dev(c, curve, group, ops, d_in, cin, n, quiet) == PTAU_OK) use_endo = 1;
+            // "not a subgroup vector" (or not even valid points: the plain path then reports them as it always did) selects
+            // the plain path; anything else — a HIP error, a failed allocation — is the caller's to see
+            char pmsg[200] = {0};
+            const int prc = run_subgroup_check_dev(c, curve, group, ops, d_in, cin, n, Err{pmsg, sizeof(pmsg)});
+            if (prc == PTAU_OK) use_endo = 1;
+            else if (prc != PTAU_E_NOT_IN_SUBGROUP && prc != PTAU_E_POINT && prc != PTAU_E_POINT_AT_INFINITY)
+                return err.fail(prc, "membership probe of BatchExpMode::Auto: %s", pmsg);
         }
     }
     const bool windowed = use_window_kernel();
@@ -1218,11 +1229,23 @@ int run_ratio_jobs(int curve, const std::vector<RatioJob> &jobs, const Err &err,
 // Phase1::verification steps (1)-(2): the jobs of the three proofs of knowledge and, for chunk 0 / Full mode, of the
 // before/after checks.  `scratch` keeps the few decompressed response elements alive until the jobs have run.
 int collect_pok_jobs(const ptau_params *p, const ptau_sizes &sz, const uint8_t *challenge, const uint8_t *response,
-                     const uint8_t *g2_s, std::vector<uint8_t> &scratch, std::vector<RatioJob> &jobs, const Err &err) {
+                     const uint8_t *g2_s, bool g2_s_from_caller, std::vector<uint8_t> &scratch, std::vector<RatioJob> &jobs,
+                     const Err &err) {
     const GroupOps *g1 = get_ops(p->curve, 1), *g2 = get_ops(p->curve, 2);
     const size_t u1 = g1->uncomp, u2 = g2->uncomp;
     // PublicKey (uncompressed): tau_g1.0, tau_g1.1, alpha_g1.0, alpha_g1.1, beta_g1.0, beta_g1.1, tau_g2, alpha_g2, beta_g2
     const uint8_t *pk = response + sz.contribution_size - sz.public_key_size;
+    {   // The PublicKey is the contributor's bytes and goes straight into pairings: canonical, ON THE CURVE and IN THE
+        // PRIME-ORDER SUBGROUP first (arkworks' checked deserialisation of the key does the same; a Miller loop on a point
+        // of another curve is not a pairing identity).  A g2_s derived by the library is a cofactor-cleared hash-to-curve
+        // output; one supplied by the caller is checked like the key.
+        int rc = ptau::host_validate_points(p->curve, 1, pk, 6);
+        if (!rc) rc = ptau::host_validate_points(p->curve, 2, pk + 6 * u1, 3);
+        if (rc) return err.fail(rc, rc == PTAU_E_NOT_IN_SUBGROUP ? "a public-key point is not in the prime-order subgroup"
+                                                                  : "a public-key point is not a valid curve point");
+        if (g2_s_from_caller && (rc = ptau::host_validate_points(p->curve, 2, g2_s, 3)))
+            return err.fail(rc, "a caller-supplied g2_s point is not a valid element of the prime-order subgroup");
+    }
     const uint8_t *pk_g1[3][2], *pk_g2[3];
     for (int x = 0; x < 3; x++) {
         pk_g1[x][0] = pk + (2 * x) * u1;
@@ -1431,10 +1454,15 @@ int verify_chunk_impl(const ptau_params *p, const uint8_t *challenge, size_t cha
             if ((rc = ptau_compute_g2_s(p->curve, chal_digest, pk, sz.public_key_size, g2_s_own.data(), errbuf, err_len))) return rc;
             g2_s = g2_s_own.data();
         }
-        if ((rc = collect_pok_jobs(p, sz, challenge, response, g2_s, pok_scratch, pok_jobs, err))) return rc;
+        if ((rc = collect_pok_jobs(p, sz, challenge, response, g2_s, g2_s_own.empty(), pok_scratch, pok_jobs, err))) return rc;
         if ((rc = run_ratio_jobs(p->curve, pok_jobs, err, device))) return rc;
     }
     if ((rc = fut_ratio.get())) return err.fail(rc, "%s", ratio_msg);
+    {   // how many pairing checks this call ran: ratio_checks == 0 under ratio_check means "not performed" (ptau.h)
+        std::lock_guard<std::mutex> tl(c->mu);
+        c->timing.ratio_checks = (uint32_t)ratio_jobs.size();
+        c->timing.pok_checks = (uint32_t)pok_jobs.size();
+    }
     // new_challenge = BLAKE2b(response) | decompressed elements
     fut_resp.wait();
     if (!chain_ok)
@@ -1460,7 +1488,8 @@ int ptau_transform_pok_and_correctness_file(const ptau_params *p, const char *ch
                                             int check_input, const char *response_path, const char *response_hash_path,
                                             int check_output, const char *new_challenge_path,
                                             const char *new_challenge_hash_path, int subgroup_check_mode, int ratio_check,
-                                            const uint8_t *g2_s, int device, char *errbuf, size_t err_len) {
+                                            const uint8_t *g2_s, const uint8_t *tau_g2_check, int device, char *errbuf,
+                                            size_t err_len) {
     Err err{errbuf, err_len};
     int rc = check_params(p, err);
     if (rc) return rc;
@@ -1479,7 +1508,7 @@ int ptau_transform_pok_and_correctness_file(const ptau_params *p, const char *ch
     VerifyDigests dg;
     resp.wait_pinned();
     rc = verify_chunk_impl(p, (const uint8_t *)ch.p, ch.len, (const uint8_t *)resp.p, resp.len, (uint8_t *)nc.p, nc.len, check_input,
-                           check_output, subgroup_check_mode, ratio_check, /*verify_pok=*/1, g2_s, nullptr, device, &dg, errbuf, err_len);
+                           check_output, subgroup_check_mode, ratio_check, /*verify_pok=*/1, g2_s, tau_g2_check, device, &dg, errbuf, err_len);
     // the reference writes challenge.hash and response.hash before it verifies: keep them on the failure paths that got that far
     if (rc == PTAU_OK || rc == PTAU_E_HASH_CHAIN || rc == PTAU_E_INVALID_RATIO || rc == PTAU_E_NOT_IN_SUBGROUP ||
         rc == PTAU_E_POINT_AT_INFINITY || rc == PTAU_E_POINT) {
@@ -1678,9 +1707,13 @@ int ptau_new_challenge_file(const ptau_params *p, const char *challenge_path, co
     return write_small_file(challenge_hash_path, digest, 64, err);
 }
 
-int ptau_combine(const ptau_params *full, uint64_t chunk_size, const uint8_t *const *responses, const size_t *response_lens,
-                 uint64_t n_chunks, uint8_t *combined, size_t combined_len, int device, char *errbuf, size_t err_len) {
-    Err err{errbuf, err_len};
+}  // extern "C"
+
+namespace {
+// Phase1::aggregation on mapped / in-memory chunk responses: every vector of every chunk is decompressed on the device
+// into its place in the Full-mode accumulator.  The 64-byte header stays zero (ptau.h, ptau_combine_file).
+int combine_impl(const ptau_params *full, uint64_t chunk_size, const uint8_t *const *responses, const size_t *response_lens,
+                 uint64_t n_chunks, uint8_t *combined, size_t combined_len, int device, const Err &err) {
     int rc = check_params(full, err);
     if (rc) return rc;
     if (full->contribution_mode != PTAU_MODE_FULL) return err.fail(PTAU_E_ARG, "combine needs Full-mode output parameters");
@@ -1690,7 +1723,8 @@ int ptau_combine(const ptau_params *full, uint64_t chunk_size, const uint8_t *co
     if (combined_len != fs.accumulator_size)
         return err.fail(PTAU_E_LEN, "combined buffer must be %llu bytes", (unsigned long long)fs.accumulator_size);
     if (n_chunks != (fs.powers_g1_length + chunk_size - 1) / chunk_size)
-        return err.fail(PTAU_E_ARG, "expected %llu chunk responses", (unsigned long long)((fs.powers_g1_length + chunk_size - 1) / chunk_size));
+        return err.fail(PTAU_E_ARG, "expected %llu chunk responses, got %llu",
+                        (unsigned long long)((fs.powers_g1_length + chunk_size - 1) / chunk_size), (unsigned long long)n_chunks);
     const GroupOps *g1 = get_ops(full->curve, 1), *g2 = get_ops(full->curve, 2);
     DeviceCtx *c;
     if ((rc = ensure_ctx(device, c, err))) return rc;
@@ -1716,10 +1750,10 @@ int ptau_combine(const ptau_params *full, uint64_t chunk_size, const uint8_t *co
             return err.fail(PTAU_E_LEN, "response of chunk %llu is %zu bytes, expected %llu", (unsigned long long)k,
                             response_lens[k], (unsigned long long)cs.contribution_size);
         const uint8_t *pi = responses[k] + 64;
-        const uint64_t n1 = cs.g1_chunk_size, n2 = cs.other_chunk_size, s = cs.start;
+        const uint64_t n1 = cs.g1_chunk_size, n2 = cs.other_chunk_size, s0 = cs.start;
         struct { const GroupOps *ops; int group; uint64_t n; uint8_t *dst; } v[5] = {
-            {g1, 1, n1, d_tau_g1 + s * g1->uncomp}, {g2, 2, n2, d_tau_g2 + s * g2->uncomp},
-            {g1, 1, n2, d_alpha + s * g1->uncomp},  {g1, 1, n2, d_beta + s * g1->uncomp},
+            {g1, 1, n1, d_tau_g1 + s0 * g1->uncomp}, {g2, 2, n2, d_tau_g2 + s0 * g2->uncomp},
+            {g1, 1, n2, d_alpha + s0 * g1->uncomp},  {g1, 1, n2, d_beta + s0 * g1->uncomp},
             {g2, 2, (uint64_t)(k == 0 ? 1 : 0), d_beta_g2}};
         for (int j = 0; j < 5; j++) {
             const uint64_t stored = j == 4 ? 1 : v[j].n;   // every chunk stores beta_g2; only chunk 0's is kept
@@ -1733,17 +1767,30 @@ int ptau_combine(const ptau_params *full, uint64_t chunk_size, const uint8_t *co
     return flush_pending_copy(c, err);   // the last vector's deferred copy
 }
 
-int ptau_transform_ratios(const ptau_params *full, const uint8_t *combined, size_t combined_len, int check_input, int device,
-                          char *errbuf, size_t err_len) {
+// pair-index range [lo, hi) of slice k of n_pairs over nd slices: contiguous, balanced to within one pair
+void slice_bounds(uint64_t n_pairs, uint64_t nd, uint64_t k, uint64_t &lo, uint64_t &hi) {
+    const uint64_t base = n_pairs / nd, extra = n_pairs % nd;
+    lo = k * base + std::min(k, extra);
+    hi = lo + base + (k < extra ? 1 : 0);
+}
+
+// Phase1::aggregate_verification over one or several devices (ptau.h: ptau_transform_ratios / _devices).
+int transform_ratios_impl(const ptau_params *full, const uint8_t *combined, size_t combined_len, int check_input,
+                          const int *devices, int n_devices, char *errbuf, size_t err_len) {
     Err err{errbuf, err_len};
     int rc = check_params(full, err);
     if (rc) return rc;
-    if (!combined) return err.fail(PTAU_E_ARG, "null pointer argument");
+    if (!combined || !devices || n_devices < 1 || n_devices > MAX_DEVICES) return err.fail(PTAU_E_ARG, "null pointer / bad device list");
+    for (int a = 0; a < n_devices; a++)
+        for (int b = a + 1; b < n_devices; b++)
+            if (devices[a] == devices[b]) return err.fail(PTAU_E_ARG, "device %d listed twice", devices[a]);
+    ptau_params fp = *full;
+    fp.contribution_mode = PTAU_MODE_FULL;   // a chunk-0 parameter block of the same ceremony is accepted
     ptau_sizes fs;
-    ptau_params_sizes(full, &fs);
+    ptau_params_sizes(&fp, &fs);
     if (combined_len != fs.accumulator_size)
         return err.fail(PTAU_E_LEN, "combined accumulator must be %llu bytes", (unsigned long long)fs.accumulator_size);
-    const GroupOps *g1 = get_ops(full->curve, 1), *g2 = get_ops(full->curve, 2);
+    const GroupOps *g1 = get_ops(fp.curve, 1), *g2 = get_ops(fp.curve, 2);
     const uint64_t n1 = fs.g1_chunk_size, n2 = fs.other_chunk_size;
     const uint8_t *v_tau_g1 = combined + 64;
     const uint8_t *v_tau_g2 = v_tau_g1 + n1 * g1->uncomp;
@@ -1751,31 +1798,182 @@ int ptau_transform_ratios(const ptau_params *full, const uint8_t *combined, size
     const uint8_t *v_beta = v_alpha + n2 * g1->uncomp;
     const uint8_t *v_beta_g2 = v_beta + n2 * g1->uncomp;
     if (n1 < 2 || n2 < 2) return err.fail(PTAU_E_ARG, "accumulator too small for ratio checks");
-    struct { const GroupOps *ops; int group; const uint8_t *ptr; uint64_t n; const char *name; } vec[4] = {
+    struct Vec { const GroupOps *ops; int group; const uint8_t *ptr; uint64_t n; const char *name; } vec[4] = {
         {g1, 1, v_tau_g1, n1, "tau_g1"}, {g2, 2, v_tau_g2, n2, "tau_g2"}, {g1, 1, v_alpha, n2, "alpha_g1"}, {g1, 1, v_beta, n2, "beta_g1"}};
-    std::vector<uint8_t> pairs(4 * 2 * (size_t)g2->uncomp);
-    for (int k = 0; k < 4; k++) {
-        if (check_input == PTAU_CHECK_FULL || check_input == PTAU_CHECK_ONLY_IN_GROUP)
-            if ((rc = ptau_subgroup_check(full->curve, vec[k].group, vec[k].ptr, 0, vec[k].n, device, errbuf, err_len))) return rc;
-        uint8_t *pa = pairs.data() + (size_t)k * 2 * g2->uncomp;
-        if ((rc = ptau_power_pairs(full->curve, vec[k].group, vec[k].ptr, 0, vec[k].n, nullptr, 0, pa, pa + g2->uncomp, device,
-                                   errbuf, err_len)))
-            return rc;
+    uint8_t seed[16];
+    {   // ONE coefficient stream for every slice of every vector: fresh secret from the OS
+        FILE *f = fopen("/dev/urandom", "rb");
+        if (!f || fread(seed, 1, 16, f) != 16) {
+            if (f) fclose(f);
+            return err.fail(PTAU_E_IO, "cannot read /dev/urandom for the random linear combination");
+        }
+        fclose(f);
+    }
+    const size_t u2 = g2->uncomp;   // >= g1->uncomp on every curve: one slot size for all partial pairs
+    const uint64_t nd = (uint64_t)n_devices;
+    std::vector<uint8_t> parts((size_t)4 * nd * 2 * u2);           // [vector][device][a | b]
+    std::vector<uint8_t> have((size_t)4 * nd, 0);
+    const bool want_sg = check_input == PTAU_CHECK_FULL || check_input == PTAU_CHECK_ONLY_IN_GROUP;
+    const int curve = fp.curve;
+    auto lane = [&](uint64_t k, char *msg, size_t msg_len) -> int {   // device k's slices, vector by vector
+        for (int v = 0; v < 4; v++) {
+            uint64_t lo, hi;
+            slice_bounds(vec[v].n - 1, nd, k, lo, hi);
+            if (hi <= lo) continue;
+            const size_t usz = vec[v].ops->uncomp;
+            const uint8_t *ptr = vec[v].ptr + lo * usz;
+            const uint64_t cnt = hi - lo + 1;   // pairs (lo, lo+1) .. (hi-1, hi): points lo .. hi
+            int r;
+            if (want_sg && (r = ptau_subgroup_check(curve, vec[v].group, ptr, 0, cnt, devices[k], msg, msg_len))) return r;
+            uint8_t *pa = parts.data() + ((size_t)v * nd + k) * 2 * u2;
+            if ((r = ptau_power_pairs(curve, vec[v].group, ptr, 0, cnt, seed, lo, pa, pa + u2, devices[k], msg, msg_len))) return r;
+            have[(size_t)v * nd + k] = 1;
+        }
+        return PTAU_OK;
+    };
+    std::vector<std::array<char, 256>> msgs(nd);
+    std::vector<std::future<int>> futs;
+    for (uint64_t k = 1; k < nd; k++)
+        futs.push_back(std::async(std::launch::async, [&, k] { msgs[k][0] = 0; return lane(k, msgs[k].data(), msgs[k].size()); }));
+    msgs[0][0] = 0;
+    rc = lane(0, msgs[0].data(), msgs[0].size());
+    int first_bad = rc ? 0 : -1;
+    for (uint64_t k = 1; k < nd; k++) {   // join every lane before anything of this frame goes away; first failure in device order
+        const int r = futs[k - 1].get();
+        if (r && first_bad < 0) { first_bad = (int)k; rc = r; }
+    }
+    if (first_bad >= 0) return err.fail(rc, "%s", msgs[first_bad].data());
+    // partial pairs -> one pair per vector (a sum of <= n_devices points: the MSM with unit scalars, on devices[0])
+    std::vector<uint8_t> pairs(4 * 2 * u2);
+    const int nl64 = (g1->fr_limbs32 + 1) / 2;
+    for (int v = 0; v < 4; v++) {
+        const size_t usz = vec[v].ops->uncomp;
+        std::vector<uint8_t> pa, pb;
+        for (uint64_t k = 0; k < nd; k++) {
+            if (!have[(size_t)v * nd + k]) continue;
+            const uint8_t *q = parts.data() + ((size_t)v * nd + k) * 2 * u2;
+            pa.insert(pa.end(), q, q + usz);
+            pb.insert(pb.end(), q + u2, q + u2 + usz);
+        }
+        const uint64_t m = pa.size() / usz;
+        uint8_t *oa = pairs.data() + (size_t)v * 2 * u2, *ob = oa + u2;
+        if (m == 1) {
+            memcpy(oa, pa.data(), usz);
+            memcpy(ob, pb.data(), usz);
+        } else {
+            std::vector<uint64_t> ones(m * nl64, 0);
+            for (uint64_t i = 0; i < m; i++) ones[i * nl64] = 1;
+            if ((rc = ptau_msm(curve, vec[v].group, pa.data(), 0, m, ones.data(), oa, 0, devices[0], errbuf, err_len))) return rc;
+            if ((rc = ptau_msm(curve, vec[v].group, pb.data(), 0, m, ones.data(), ob, 0, devices[0], errbuf, err_len))) return rc;
+        }
     }
     // G1 vectors against (tauG2[0], tauG2[1]); tauG2 against (tauG1[0], tauG1[1]); betaG2 against betaG1[0]:
     // five same-ratio checks, one launch of the pairing kernel
     std::vector<RatioJob> jobs;
     for (int k : {0, 2, 3}) {
-        const uint8_t *pa = pairs.data() + (size_t)k * 2 * g2->uncomp;
-        jobs.push_back({pa, pa + g2->uncomp, v_tau_g2, v_tau_g2 + g2->uncomp, std::string("power ratio check failed for ") + vec[k].name});
+        const uint8_t *pa = pairs.data() + (size_t)k * 2 * u2;
+        jobs.push_back({pa, pa + u2, v_tau_g2, v_tau_g2 + g2->uncomp, std::string("power ratio check failed for ") + vec[k].name});
     }
     {
-        const uint8_t *pa = pairs.data() + (size_t)1 * 2 * g2->uncomp;
-        jobs.push_back({v_tau_g1, v_tau_g1 + g1->uncomp, pa, pa + g2->uncomp, "power ratio check failed for tau_g2"});
+        const uint8_t *pa = pairs.data() + (size_t)1 * 2 * u2;
+        jobs.push_back({v_tau_g1, v_tau_g1 + g1->uncomp, pa, pa + u2, "power ratio check failed for tau_g2"});
     }
     // e(G1, betaG2) == e(betaG1[0], G2): (tauG1[0], betaG1[0]) ~ (tauG2[0], betaG2)
     jobs.push_back({v_tau_g1, v_beta, v_tau_g2, v_beta_g2, "beta_g2 is not consistent with beta_g1[0]"});
-    return run_ratio_jobs(full->curve, jobs, err, device);
+    return run_ratio_jobs(curve, jobs, err, devices[0]);
+}
+
+// one path per line (control.rs:547-557 writes "{}\n" per chunk); blank lines and a trailing '\r' are tolerated
+int read_list_file(const char *path, std::vector<std::string> &out, const Err &err) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return err.fail(PTAU_E_IO, "cannot open %s: %s", path, strerror(errno));
+    std::string cur;
+    int ch;
+    auto flush = [&] {
+        while (!cur.empty() && (cur.back() == '\r' || cur.back() == ' ')) cur.pop_back();
+        if (!cur.empty()) out.push_back(cur);
+        cur.clear();
+    };
+    while ((ch = fgetc(f)) != EOF) {
+        if (ch == '\n') flush();
+        else cur.push_back((char)ch);
+    }
+    flush();
+    fclose(f);
+    return PTAU_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int ptau_combine(const ptau_params *full, uint64_t chunk_size, const uint8_t *const *responses, const size_t *response_lens,
+                 uint64_t n_chunks, uint8_t *combined, size_t combined_len, int device, char *errbuf, size_t err_len) {
+    return combine_impl(full, chunk_size, responses, response_lens, n_chunks, combined, combined_len, device, Err{errbuf, err_len});
+}
+
+int ptau_combine_file(const ptau_params *chunk0, const char *response_list_path, const char *combined_path, int device,
+                      char *errbuf, size_t err_len) {
+    Err err{errbuf, err_len};
+    int rc = check_params(chunk0, err);
+    if (rc) return rc;
+    if (!response_list_path || !combined_path) return err.fail(PTAU_E_ARG, "null pointer argument");
+    if (chunk0->contribution_mode != PTAU_MODE_CHUNKED)
+        return err.fail(PTAU_E_ARG, "combine takes the parameters of a chunk (create_parameters_for_chunk(.., 0))");
+    ptau_params full = *chunk0;
+    full.contribution_mode = PTAU_MODE_FULL;
+    full.chunk_index = 0;
+    ptau_sizes fs;
+    ptau_params_sizes(&full, &fs);
+    std::vector<std::string> paths;
+    if ((rc = read_list_file(response_list_path, paths, err))) return rc;
+    const uint64_t n_chunks = (fs.powers_g1_length + chunk0->chunk_size - 1) / chunk0->chunk_size;
+    if (paths.size() != n_chunks)
+        return err.fail(PTAU_E_ARG, "%s lists %zu responses, the ceremony has %llu chunks", response_list_path, paths.size(),
+                        (unsigned long long)n_chunks);
+    std::vector<std::unique_ptr<MappedFile>> maps;
+    std::vector<const uint8_t *> ptrs;
+    std::vector<size_t> lens;
+    const bool pin = n_chunks <= 64;   // one populate / register thread per mapping: bounded
+    for (auto &pth : paths) {
+        maps.emplace_back(new MappedFile());
+        if ((rc = maps.back()->open_ro(pth.c_str(), err, pin, device))) return rc;
+        ptrs.push_back((const uint8_t *)maps.back()->p);
+        lens.push_back(maps.back()->len);
+    }
+    MappedFile out;
+    if ((rc = out.create_new(combined_path, fs.accumulator_size, err, device))) return rc;
+    for (auto &m : maps) m->wait_pinned();
+    if ((rc = combine_impl(&full, chunk0->chunk_size, ptrs.data(), lens.data(), n_chunks, (uint8_t *)out.p, out.len, device, err))) return rc;
+    if (out.populate.valid()) out.populate.wait();
+    if (msync(out.p, out.len, MS_SYNC)) return err.fail(PTAU_E_IO, "msync failed: %s", strerror(errno));
+    return PTAU_OK;
+}
+
+int ptau_transform_ratios(const ptau_params *full, const uint8_t *combined, size_t combined_len, int check_input, int device,
+                          char *errbuf, size_t err_len) {
+    return transform_ratios_impl(full, combined, combined_len, check_input, &device, 1, errbuf, err_len);
+}
+
+int ptau_transform_ratios_devices(const ptau_params *full, const uint8_t *combined, size_t combined_len, int check_input,
+                                  const int *devices, int n_devices, char *errbuf, size_t err_len) {
+    return transform_ratios_impl(full, combined, combined_len, check_input, devices, n_devices, errbuf, err_len);
+}
+
+int ptau_transform_ratios_file_devices(const ptau_params *full, const char *combined_path, int check_input, const int *devices,
+                                       int n_devices, char *errbuf, size_t err_len) {
+    Err err{errbuf, err_len};
+    int rc = check_params(full, err);
+    if (rc) return rc;
+    if (!combined_path || !devices || n_devices < 1) return err.fail(PTAU_E_ARG, "null pointer / bad device list");
+    MappedFile f;
+    if ((rc = f.open_ro(combined_path, err, /*pin=*/true, devices[0]))) return rc;
+    f.wait_pinned();
+    return transform_ratios_impl(full, (const uint8_t *)f.p, f.len, check_input, devices, n_devices, errbuf, err_len);
+}
+
+int ptau_transform_ratios_file(const ptau_params *full, const char *combined_path, int check_input, int device, char *errbuf,
+                               size_t err_len) {
+    return ptau_transform_ratios_file_devices(full, combined_path, check_input, &device, 1, errbuf, err_len);
 }
 
 int ptau_verify_pok(const ptau_params *p, const uint8_t *challenge, size_t challenge_len, const uint8_t *response,
@@ -1789,6 +1987,7 @@ int ptau_verify_pok(const ptau_params *p, const uint8_t *challenge, size_t chall
     if (challenge_len != sz.accumulator_size || response_len != sz.contribution_size)
         return err.fail(PTAU_E_LEN, "challenge/response sizes do not match the parameters");
     std::vector<uint8_t> own;
+    const bool g2_s_from_caller = g2_s != nullptr;
     if (!g2_s) {   // derive the three compute_g2_s points from BLAKE2b(challenge) and the public key
         uint8_t digest[64];
         ptau_blake2b512(challenge, challenge_len, digest);
@@ -1800,7 +1999,7 @@ int ptau_verify_pok(const ptau_params *p, const uint8_t *challenge, size_t chall
     }
     std::vector<uint8_t> scratch;
     std::vector<RatioJob> jobs;
-    if ((rc = collect_pok_jobs(p, sz, challenge, response, g2_s, scratch, jobs, err))) return rc;
+    if ((rc = collect_pok_jobs(p, sz, challenge, response, g2_s, g2_s_from_caller, scratch, jobs, err))) return rc;
     return run_ratio_jobs(p->curve, jobs, err);
 }
 

@@ -17,6 +17,7 @@
 // g2_s points where it has them.
 #include <cstdio>
 #include <cstring>
+#include <future>
 #include <string>
 #include <vector>
 
@@ -280,12 +281,57 @@ using Bw6K = KeyGen<GroupTypes<Bw6FqR29, Bw6Fr, Bw6G1Cfg>, GroupTypes<Bw6FqR29, 
 using Mnt4K = KeyGen<GroupTypes<Mnt4FqR29, Mnt4Fr, Mnt4G1Cfg>, GroupTypes<Mnt4FqR29, Mnt4Fr, Mnt4G2Cfg>>;
 using Mnt6K = KeyGen<GroupTypes<Mnt6FqR29, Mnt6Fr, Mnt6G1Cfg>, GroupTypes<Mnt6FqR29, Mnt6Fr, Mnt6G2Cfg>>;
 
+// Validity of serialized UNCOMPRESSED points as arkworks' checked deserialisation would see them: canonical coordinates,
+// on the curve, in the prime-order subgroup ([r]P == O; cofactor-1 groups need no multiplication).  The point at infinity
+// passes here: check_same_ratio rejects it.  One host thread per point (the few points of a PublicKey).
+template <class G>
+int validate_points(const uint8_t *pts, size_t n) {
+    using H = HostGroup<G>;
+    using F = typename G::F;
+    using Cfg = typename H::Cfg;
+    using Fr = typename G::Fr;
+    std::vector<std::future<int>> futs;
+    for (size_t i = 0; i < n; i++)
+        futs.push_back(std::async(std::launch::async, [pts, i]() -> int {
+            typename G::A p;
+            if (!read_uncompressed<F>(pts + i * G::UNCOMP, p)) return PTAU_E_POINT;
+            if (p.inf) return PTAU_OK;
+            if (!(F::sqr(p.y) == curve_rhs<F, Cfg>(p.x))) return PTAU_E_POINT;
+            if (Cfg::COFACTOR_BITS == 1 && Cfg::COFACTOR[0] == 1u) return PTAU_OK;
+            return H::mul_words(p, Fr::Params::MOD, Fr::Params::BITS).is_inf() ? PTAU_OK : PTAU_E_NOT_IN_SUBGROUP;
+        }));
+    int rc = PTAU_OK;
+    for (auto &f : futs) {
+        const int r = f.get();
+        if (r && !rc) rc = r;
+    }
+    return rc;
+}
+
 int fail(char *buf, size_t len, int code, const char *msg) {
     if (buf && len) snprintf(buf, len, "%s", msg);
     return code;
 }
 
 }  // namespace
+
+namespace ptau {
+// capi.hip: the PublicKey at the tail of a response and a caller-supplied g2_s are attacker-controlled bytes that go
+// straight into pairings — validated first, as the reference's checked deserialisation of the PublicKey does.
+int host_validate_points(int curve, int group, const uint8_t *pts, size_t n) {
+    switch (curve * 2 + (group - 1)) {
+    case 0: return validate_points<GroupTypes<BlsFqR29, BlsFr, BlsG1Cfg>>(pts, n);
+    case 1: return validate_points<GroupTypes<BlsFqR29, BlsFr, BlsG2Cfg>>(pts, n);
+    case 2: return validate_points<GroupTypes<Bw6FqR29, Bw6Fr, Bw6G1Cfg>>(pts, n);
+    case 3: return validate_points<GroupTypes<Bw6FqR29, Bw6Fr, Bw6G2Cfg>>(pts, n);
+    case 4: return validate_points<GroupTypes<Mnt4FqR29, Mnt4Fr, Mnt4G1Cfg>>(pts, n);
+    case 5: return validate_points<GroupTypes<Mnt4FqR29, Mnt4Fr, Mnt4G2Cfg>>(pts, n);
+    case 6: return validate_points<GroupTypes<Mnt6FqR29, Mnt6Fr, Mnt6G1Cfg>>(pts, n);
+    case 7: return validate_points<GroupTypes<Mnt6FqR29, Mnt6Fr, Mnt6G2Cfg>>(pts, n);
+    }
+    return PTAU_E_ARG;
+}
+}  // namespace ptau
 
 extern "C" {
 

@@ -237,16 +237,18 @@ def verification_and_decompress(challenge: bytes, response: bytes, parameters: P
 def transform_pok_and_correctness(challenge_filename, challenge_hash_filename, check_input_correctness, response_filename,
                                   response_hash_filename, check_output_correctness, new_challenge_filename,
                                   new_challenge_hash_filename, subgroup_check_mode, ratio_check,
-                                  parameters: Phase1Parameters, g2_s: bytes = None, device: int = 0):
+                                  parameters: Phase1Parameters, g2_s: bytes = None, tau_g2_check: bytes = None, device: int = 0):
     """phase1_cli::transform_pok_and_correctness (contribute.rs:968-986), the reference's eleven arguments in its order.
-    Proofs of knowledge are always checked; g2_s=None lets the library derive the compute_g2_s points itself."""
+    Proofs of knowledge are always checked; g2_s=None lets the library derive the compute_g2_s points itself.
+    tau_g2_check: (tauG2[0] | tauG2[1]) uncompressed, of the same contribution — lets ratio_check cover a tauG1-only chunk;
+    without it last_timing()["ratio_checks"] == 0 reports that such a chunk's power ratios were left to transform_ratios."""
     L = _lib.load_library()
     eb = _lib.errbuf()
     rc = L.ptau_transform_pok_and_correctness_file(
         ctypes.byref(parameters._c()), os.fsencode(challenge_filename), os.fsencode(challenge_hash_filename),
         int(check_input_correctness), os.fsencode(response_filename), os.fsencode(response_hash_filename),
         int(check_output_correctness), os.fsencode(new_challenge_filename), os.fsencode(new_challenge_hash_filename),
-        int(subgroup_check_mode), int(bool(ratio_check)), g2_s, device, eb, len(eb))
+        int(subgroup_check_mode), int(bool(ratio_check)), g2_s, tau_g2_check, device, eb, len(eb))
     _lib.check(rc, eb)
 
 
@@ -438,6 +440,41 @@ def transform_ratios(combined: bytes, check_input_correctness, full_parameters: 
     eb = _lib.errbuf()
     _lib.check(L.ptau_transform_ratios(ctypes.byref(full_parameters._c()), combined, len(combined),
                                        int(check_input_correctness), device, eb, len(eb)), eb)
+
+
+def combine_file(response_list_filename, combined_filename, parameters: Phase1Parameters, device=0):
+    """phase1_cli::combine(response_list_filename, combined_filename, &parameters) — control.rs:564-568,
+    verify_transcript.rs:603-607: `parameters` = create_parameters_for_chunk(.., 0); the list file holds one chunk-response path
+    per line; `combined_filename` is created (create_new)."""
+    L = _lib.load_library()
+    eb = _lib.errbuf()
+    _lib.check(L.ptau_combine_file(ctypes.byref(parameters._c()), os.fsencode(response_list_filename),
+                                   os.fsencode(combined_filename), device, eb, len(eb)), eb)
+
+
+def transform_ratios_file(combined_filename, check_input_correctness, full_parameters: Phase1Parameters, device=0, devices=None):
+    """phase1_cli::transform_ratios(combined_filename, check_input_correctness, &full_parameters) — control.rs:587-591,
+    verify_transcript.rs:646-653, 811-822.  devices=[ordinals]: the reductions are spread over several GPUs from this one
+    process (ptau_transform_ratios_file_devices)."""
+    L = _lib.load_library()
+    eb = _lib.errbuf()
+    if devices is None:
+        rc = L.ptau_transform_ratios_file(ctypes.byref(full_parameters._c()), os.fsencode(combined_filename),
+                                          int(check_input_correctness), device, eb, len(eb))
+    else:
+        arr = (ctypes.c_int * len(devices))(*devices)
+        rc = L.ptau_transform_ratios_file_devices(ctypes.byref(full_parameters._c()), os.fsencode(combined_filename),
+                                                  int(check_input_correctness), arr, len(devices), eb, len(eb))
+    _lib.check(rc, eb)
+
+
+def transform_ratios_devices(combined: bytes, check_input_correctness, full_parameters: Phase1Parameters, devices):
+    """transform_ratios on a buffer with the vector reductions spread over `devices` from this one process."""
+    L = _lib.load_library()
+    eb = _lib.errbuf()
+    arr = (ctypes.c_int * len(devices))(*devices)
+    _lib.check(L.ptau_transform_ratios_devices(ctypes.byref(full_parameters._c()), combined, len(combined),
+                                               int(check_input_correctness), arr, len(devices), eb, len(eb)), eb)
 
 
 def transform_ratios_sharded(combined, full_parameters: Phase1Parameters, dist=None, device=0, seed: bytes = None) -> None:

@@ -1,0 +1,258 @@
+"""GPU parity tests of the whole-transcript tail through the FILE-level entry points, with the reference's argument lists:
+phase1_cli::combine(response_list, combined, &chunk_parameters) (control.rs:564-568, verify_transcript.rs:603-607), the beacon
+contribution in Full mode seeded by the 32-byte beacon hash (verify_transcript.rs:675-696, control.rs:781-808; all-zero in
+e2e/e2ephase1.sh:33-34), transform_pok_and_correctness(Full) (verify_transcript.rs:745-776) and
+transform_ratios(file, check, &full_parameters) (verify_transcript.rs:811-822, control.rs:587-591) — every artefact
+against oracle/pyref; plus the e2e script's MNT shapes (e2e/e2ephase1.sh:24-25) and malformed public keys."""
+import os
+import random
+
+import pytest
+
+from conftest import ROOT, initial_challenge
+from oracle.pyref import keygen as K
+from oracle.pyref import phase1 as P, serde
+from oracle.pyref.curves import CURVES
+from oracle.pyref.ec import Group
+
+pytestmark = pytest.mark.gpu
+
+BEACON = bytes(32)   # e2e/e2ephase1.sh:33-34
+
+
+def _write_initial(pkg, name, prm, path):
+    ch = initial_challenge(pkg, name, prm)
+    open(path, "wb").write(ch)
+    open(path + ".hash", "wb").write(pkg.calculate_hash(ch))
+    return ch
+
+
+def _round_of_chunks(pkg, name, power, cs, seed, d, verify=None, cref=None):
+    """Every chunk of one round contributed from ONE seed (contribute.rs:783-789) through the file-level calls; returns the
+    response paths, the chunk parameters (ours, oracle's) and the round's private key."""
+    c = CURVES[name]
+    full = pkg.Phase1Parameters.new_full(name, 0, power, cs)
+    n_chunks = -(-full.powers_g1_length // cs)
+    paths, oparams, key = [], [], None
+    for i in range(n_chunks):
+        prm = pkg.Phase1Parameters.new_chunk(name, 0, i, cs, 0, power, cs)
+        f = lambda s: os.path.join(d, "chunk%d.%s" % (i, s))
+        ch = _write_initial(pkg, name, prm, f("challenge"))
+        pkg.phase1_cli.contribute_seeded(f("challenge"), f("challenge.h"), f("response"), f("response.hash"), pkg.CheckForCorrectness.No,
+                                         pkg.BatchExpMode.Auto, prm, seed)
+        resp = open(f("response"), "rb").read()
+        k = pkg.phase1_cli.key_generation(name, seed, pkg.calculate_hash(ch))
+        key = key or (k.tau, k.alpha, k.beta)
+        assert (k.tau, k.alpha, k.beta) == key          # the same seed -> the same private key in every chunk
+        assert resp[:64] == pkg.calculate_hash(ch) and resp[-prm.public_key_size:] == k.public_key
+        if cref is not None:
+            ref = cref.computation(name, 0, i, cs, power, ch, k.tau, k.alpha, k.beta, nthreads=8)
+            end = prm.contribution_size - prm.public_key_size
+            assert resp[64:end] == ref[64:end], "chunk %d differs from the C oracle" % i
+        if verify is not None and i in verify:
+            pkg.transform_pok_and_correctness(f("challenge"), f("vc.hash"), pkg.CheckForCorrectness.No, f("response"), f("vr.hash"),
+                                              pkg.CheckForCorrectness.OnlyNonZero, f("new_challenge"), f("new_challenge.hash"),
+                                              pkg.SubgroupCheckMode.Auto, True, prm)
+            nc = open(f("new_challenge"), "rb").read()
+            assert nc[:64] == pkg.calculate_hash(resp) and open(f("new_challenge.hash"), "rb").read() == pkg.calculate_hash(nc)
+        paths.append(f("response"))
+        oparams.append(P.Params(c, P.CHUNKED, i, cs, power, cs))
+    return paths, oparams, key, full
+
+
+@pytest.mark.parametrize("name", ["bls12_377", "bw6"])
+def test_beacon_chain_file_level(name, pkg, tmp_path):
+    """tiny ceremony -> combine FILE -> Full-mode contribute with the all-zero beacon seed -> transform_pok_and_correctness
+    (Full) -> transform_ratios FILE: verify_transcript.rs:596-696, 745-776, 811-822, every artefact vs oracle/pyref."""
+    c = CURVES[name]
+    power, cs = 3, 4
+    d = str(tmp_path)
+    f = lambda s: os.path.join(d, s)
+    paths, oparams, key, full = _round_of_chunks(pkg, name, power, cs, bytes([9]) * 64, d)
+    prm0 = pkg.Phase1Parameters.new_chunk(name, 0, 0, cs, 0, power, cs)
+    open(f("response_list"), "w").write("".join(p + "\n" for p in paths))
+    pkg.phase1_cli.combine_file(f("response_list"), f("combined"), prm0)
+    combined = open(f("combined"), "rb").read()
+    pfull = P.Params(c, P.FULL, 0, cs, power, cs)
+    assert combined == P.aggregation(oparams, [open(p, "rb").read() for p in paths], pfull)
+    assert combined[:64] == bytes(64)                   # set_len + aggregation: the header is never written (ptau.h)
+    with pytest.raises(pkg.PtauError) as e:             # create_new: the caller removes a stale file first (control.rs:560)
+        pkg.phase1_cli.combine_file(f("response_list"), f("combined"), prm0)
+    assert e.value.code == -9
+    with pytest.raises(pkg.PtauError) as e:             # a list that does not name every chunk
+        open(f("short_list"), "w").write(paths[0] + "\n")
+        pkg.phase1_cli.combine_file(f("short_list"), f("combined2"), prm0)
+    assert e.value.code == -1
+    pkg.phase1_cli.transform_ratios_file(f("combined"), pkg.CheckForCorrectness.Full, full)
+    pkg.phase1_cli.transform_ratios_file(f("combined"), pkg.CheckForCorrectness.No, full, devices=[0])
+    # the beacon: phase1_cli::contribute(COMBINED, COMBINED_HASH, .._VERIFIED_POK_AND_CORRECTNESS, .., rng = beacon)
+    pkg.phase1_cli.contribute_seeded(f("combined"), f("combined.hash"), f("beacon_response"), f("beacon_response.hash"),
+                                     pkg.CheckForCorrectness.No, pkg.BatchExpMode.Auto, full, BEACON)
+    digest = P.calculate_hash(combined)
+    assert open(f("combined.hash"), "rb").read() == digest
+    tau, alpha, beta, pk, _ = K.key_generation(c, BEACON, digest)
+    want = digest + P.computation(pfull, combined, tau, alpha, beta) + pk
+    got = open(f("beacon_response"), "rb").read()
+    assert got == want
+    assert open(f("beacon_response.hash"), "rb").read() == P.calculate_hash(want)      # the transcript's final hash (:717-729)
+    pkg.transform_pok_and_correctness(f("combined"), f("v.combined.hash"), pkg.CheckForCorrectness.No, f("beacon_response"),
+                                      f("v.beacon_response.hash"), pkg.CheckForCorrectness.OnlyNonZero, f("beacon_new_challenge"),
+                                      f("beacon_new_challenge.hash"), pkg.SubgroupCheckMode.Auto, True, full)
+    tm = pkg.phase1_cli.last_timing(0)
+    assert tm["ratio_checks"] == 4 and tm["pok_checks"] == 8
+    nc = open(f("beacon_new_challenge"), "rb").read()
+    assert nc == P.new_challenge_from_response(pfull, want)
+    assert open(f("beacon_new_challenge.hash"), "rb").read() == P.calculate_hash(nc)
+    pkg.phase1_cli.transform_ratios_file(f("beacon_new_challenge"), pkg.CheckForCorrectness.No, full)
+    # element 1 of tauG1 is now (tau_round * tau_beacon) G
+    G1 = Group(c, 1)
+    u = G1.uncomp_size
+    assert nc[64 + u:64 + 2 * u] == serde.write_point(G1, G1.mul(G1.gen, key[0] * tau % c.r), False)
+    # a tampered accumulator file is refused by the file-level check
+    bad = bytearray(nc)
+    bad[64 + 2 * u:64 + 3 * u], bad[64 + 3 * u:64 + 4 * u] = bad[64 + 3 * u:64 + 4 * u], bad[64 + 2 * u:64 + 3 * u]
+    open(f("tampered"), "wb").write(bytes(bad))
+    with pytest.raises(pkg.PtauError) as e:
+        pkg.phase1_cli.transform_ratios_file(f("tampered"), pkg.CheckForCorrectness.No, full)
+    assert e.value.code == -6
+    with pytest.raises(pkg.PtauError) as e:
+        pkg.phase1_cli.transform_ratios_devices(bytes(bad), pkg.CheckForCorrectness.No, full, [0])
+    assert e.value.code == -6
+
+
+@pytest.mark.parametrize("name,cs", [("mnt4_753", 1 << 12), ("mnt6_753", 1 << 8)])
+def test_e2e_script_mnt_shapes_file_level(name, cs, pkg, cref, tmp_path):
+    """The shapes e2e/e2ephase1.sh:24-25 really runs — MNT4-753 --powers 12 --chunk-size 12 (2 chunks), MNT6-753 --powers 12
+    --chunk-size 8 (32 chunks: 16 full + 16 tauG1-only) — through the file-level entry points with caller-supplied
+    generators: contribute from a seed (bit-exact vs the C oracle), transform_pok_and_correctness with ratio_check on the
+    first / last full and tauG1-only chunks, combine FILE vs the oracle's aggregation on sampled ranges, transform_ratios FILE."""
+    c = CURVES[name]
+    power = 12
+    d = str(tmp_path)
+    f = lambda s: os.path.join(d, s)
+    full = pkg.Phase1Parameters.new_full(name, 0, power, cs)
+    n_chunks = -(-full.powers_g1_length // cs)
+    half = n_chunks // 2
+    verify = {0, half - 1, half, n_chunks - 1}
+    paths, oparams, key, full = _round_of_chunks(pkg, name, power, cs, bytes([3]) * 64, d, verify=verify, cref=cref)
+    # a tauG1-only chunk: ratio_check has no G2 pair of its own (ratio_checks == 0 says "not performed") unless the caller
+    # hands over (tauG2[0], tauG2[1]) of the same contribution
+    i = n_chunks - 1
+    prm = pkg.Phase1Parameters.new_chunk(name, 0, i, cs, 0, power, cs)
+    assert pkg.phase1_cli.last_timing(0)["ratio_checks"] == 0
+    G1, G2 = Group(c, 1), Group(c, 2)
+    nc0 = open(os.path.join(d, "chunk0.new_challenge"), "rb").read()
+    prm0 = pkg.Phase1Parameters.new_chunk(name, 0, 0, cs, 0, power, cs)
+    off2 = 64 + prm0.g1_chunk_size * G1.uncomp_size
+    pair = nc0[off2:off2 + 2 * G2.uncomp_size]
+    g = lambda s: os.path.join(d, "chunk%d.%s" % (i, s))
+    pkg.transform_pok_and_correctness(g("challenge"), g("vc2.hash"), pkg.CheckForCorrectness.No, g("response"), g("vr2.hash"),
+                                      pkg.CheckForCorrectness.OnlyNonZero, g("new_challenge2"), g("new_challenge2.hash"),
+                                      pkg.SubgroupCheckMode.Auto, True, prm, tau_g2_check=pair)
+    assert pkg.phase1_cli.last_timing(0)["ratio_checks"] == 1
+    open(f("response_list"), "w").write("".join(p + "\n" for p in paths))
+    pkg.phase1_cli.combine_file(f("response_list"), f("combined"), prm0)
+    combined = open(f("combined"), "rb").read()
+    assert len(combined) == full.accumulator_size and combined[:64] == bytes(64)
+    # sampled against the oracle's decompression: head and tail of tauG1, head of tauG2, the lone betaG2
+    r0, rl = open(paths[0], "rb").read(), open(paths[-1], "rb").read()
+    u1, c1, u2, c2 = G1.uncomp_size, G1.comp_size, G2.uncomp_size, G2.comp_size
+    dec = lambda G, b, n: serde.write_batch(G, serde.read_batch(G, b, True), False)
+    assert combined[64:64 + 4 * u1] == dec(G1, r0[64:64 + 4 * c1], 4)
+    nl = oparams[-1].g1_chunk_size
+    end1 = 64 + full.powers_g1_length * u1
+    assert combined[end1 - 3 * u1:end1] == dec(G1, rl[64 + (nl - 3) * c1:64 + nl * c1], 3)
+    assert combined[end1:end1 + 2 * u2] == dec(G2, r0[64 + cs * c1:64 + cs * c1 + 2 * c2], 2)
+    lay = {nm: o for (nm, grp, o, cnt) in oparams[0].layout(True)[0]}
+    assert combined[-u2:] == dec(G2, r0[lay["beta_g2"]:lay["beta_g2"] + c2], 1)
+    pkg.phase1_cli.transform_ratios_file(f("combined"), pkg.CheckForCorrectness.No, full)
+    # tauG1[1] = tau G
+    assert combined[64 + u1:64 + 2 * u1] == serde.write_point(G1, G1.mul(G1.gen, key[0]), False)
+
+
+def test_malformed_public_key_is_refused(pkg, tmp_path):
+    """The PublicKey at the tail of a response is the contributor's bytes: an off-curve point, a point outside the
+    prime-order subgroup, or a bad caller-supplied g2_s never reaches the pairing (PTAU_E_POINT / PTAU_E_NOT_IN_SUBGROUP)."""
+    name, power, cs = "bls12_377", 3, 8
+    c = CURVES[name]
+    G1, G2 = Group(c, 1), Group(c, 2)
+    d = str(tmp_path)
+    f = lambda s: os.path.join(d, s)
+    prm = pkg.Phase1Parameters.new_chunk(name, 0, 0, cs, 0, power, cs)
+    _write_initial(pkg, name, prm, f("challenge"))
+    pkg.phase1_cli.contribute_seeded(f("challenge"), f("challenge.h"), f("response"), f("response.hash"), pkg.CheckForCorrectness.No,
+                                     pkg.BatchExpMode.Auto, prm, bytes([5]) * 64)
+    resp = open(f("response"), "rb").read()
+    pk_off = prm.contribution_size - prm.public_key_size
+    u1, u2 = G1.uncomp_size, G2.uncomp_size
+    rng = random.Random(11)
+
+    def run(tag, response, g2_s=None):
+        open(f(tag), "wb").write(response)
+        pkg.transform_pok_and_correctness(f("challenge"), f(tag + ".ch"), pkg.CheckForCorrectness.No, f(tag), f(tag + ".rh"),
+                                          pkg.CheckForCorrectness.OnlyNonZero, f(tag + ".nc"), f(tag + ".nc.hash"),
+                                          pkg.SubgroupCheckMode.Auto, True, prm, g2_s=g2_s)
+    run("honest", resp)
+    x, y = serde.read_point(G1, resp[pk_off:pk_off + u1], False)
+    cases = [
+        ("g1_off_curve", pk_off, serde.write_point(G1, (x, G1.F.add(y, G1.F.one())), False), -3),
+        ("g1_off_subgroup", pk_off + u1, serde.write_point(G1, _off_subgroup(G1, rng), False), -5),
+        ("g2_off_subgroup", pk_off + 6 * u1 + u2, serde.write_point(G2, _off_subgroup(G2, rng), False), -5),
+    ]
+    for tag, off, pt, code in cases:
+        bad = bytearray(resp)
+        bad[off:off + len(pt)] = pt
+        with pytest.raises(pkg.PtauError) as e:
+            run(tag, bytes(bad))
+        assert e.value.code == code, tag
+        with pytest.raises(pkg.PtauError) as e:      # the standalone (host) form validates too
+            pkg.phase1_cli.verify_pok(open(f("challenge"), "rb").read(), bytes(bad), None, prm)
+        assert e.value.code == code, tag
+    # caller-supplied g2_s: honest points pass, one off the subgroup is refused
+    g2_s = pkg.phase1_cli.compute_g2_s(name, pkg.calculate_hash(open(f("challenge"), "rb").read()), resp[pk_off:])
+    run("honest_g2s", resp, g2_s=g2_s)
+    bad_s = bytearray(g2_s)
+    bad_s[u2:2 * u2] = serde.write_point(G2, _off_subgroup(G2, rng), False)
+    with pytest.raises(pkg.PtauError) as e:
+        run("bad_g2s", resp, g2_s=bytes(bad_s))
+    assert e.value.code == -5
+
+
+def _off_subgroup(G, rng):
+    F = G.F
+    while True:
+        x = tuple(rng.randrange(G.curve.q) for _ in range(F.deg))
+        rhs = F.add(F.add(F.mul(F.sqr(x), x), F.mul(G.a, x)), G.b)
+        y = F.sqrt(rhs)
+        if y is not None and not G.in_subgroup((x, y)):
+            return (x, y)
+
+
+def test_abi_caller_whole_transcript_tail(tmp_path):
+    """The same tail driven by the plain-C caller (no Python between caller and library): every chunk, combine FILE, beacon,
+    Full-mode verification, transform_ratios FILE over every device — hashes vs oracle/pyref."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "native", "abi_caller")
+    if not os.path.exists(exe):
+        pytest.skip("abi_caller not built (run __graft_entry__.build())")
+    name, power, cs = "bls12_377", 3, 4
+    c = CURVES[name]
+    seed = bytes(range(40, 104))
+    r = subprocess.run([exe, str(tmp_path), str(c.curve_id), str(power), str(cs), "0", seed.hex(), "tail"], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    out = dict(l.split("=", 1) for l in r.stdout.strip().splitlines())
+    assert out["tail"] == "ok" and out["second_combine_rc"] == "-9"
+    rd = lambda s: open(os.path.join(str(tmp_path), s), "rb").read()
+    pfull = P.Params(c, P.FULL, 0, cs, power, cs)
+    n_chunks = pfull.num_chunks()
+    oparams = [P.Params(c, P.CHUNKED, i, cs, power, cs) for i in range(n_chunks)]
+    combined = rd("combined")
+    assert combined == P.aggregation(oparams, [rd("chunk%d.response" % i) for i in range(n_chunks)], pfull)
+    digest = P.calculate_hash(combined)
+    assert out["combined_hash"] == digest.hex()
+    tau, alpha, beta, pk, _ = K.key_generation(c, BEACON, digest)
+    want = digest + P.computation(pfull, combined, tau, alpha, beta) + pk
+    assert rd("combined_verified_pok_and_correctness") == want and out["beacon_response_hash"] == P.calculate_hash(want).hex()
+    nc = rd("combined_verified_pok_and_correctness_new_challenge")
+    assert nc == P.new_challenge_from_response(pfull, want) and out["beacon_new_challenge_hash"] == P.calculate_hash(nc).hex()

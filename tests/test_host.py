@@ -376,3 +376,41 @@ def test_carry_free_field_arithmetic_on_host():
         assert g(5) == (5 * a - 8 * b) % p
         assert g(6) == (62 * a + 32 * b) % p
         assert o[7 * B] == (1 | (2 if a == b else 0) | 4 | (8 if a == 0 else 0)), (a, b, o[7 * B])
+
+
+def test_file_level_tail_argument_checks_without_gpu(pkg, tmp_path):
+    """phase1_cli::combine / transform_ratios in their file forms (control.rs:564-568, 587-591): argument and I/O errors are
+    reported before anything touches a device — a list that names the wrong number of responses, a missing file, Full-mode
+    parameters handed to combine, a device listed twice."""
+    import ctypes
+    L = pkg.load_library()
+    prm0 = pkg.Phase1Parameters.new_chunk("bls12_377", 0, 0, 4, 0, 3, 4)
+    full = pkg.Phase1Parameters.new_full("bls12_377", 0, 3, 4)
+    lst = tmp_path / "list"
+    lst.write_text("a\nb\n")                      # 2 paths, the ceremony has 4 chunks
+    with pytest.raises(pkg.PtauError) as e:
+        pkg.phase1_cli.combine_file(str(lst), str(tmp_path / "combined"), prm0)
+    assert e.value.code == -1 and "4 chunks" in str(e.value)
+    with pytest.raises(pkg.PtauError) as e:
+        pkg.phase1_cli.combine_file(str(tmp_path / "missing"), str(tmp_path / "combined"), prm0)
+    assert e.value.code == -9
+    with pytest.raises(pkg.PtauError) as e:
+        pkg.phase1_cli.combine_file(str(lst), str(tmp_path / "combined"), full)
+    assert e.value.code == -1
+    lst.write_text("".join(str(tmp_path / ("r%d" % i)) + "\r\n\n" for i in range(4)))   # CRLF and blank lines tolerated
+    with pytest.raises(pkg.PtauError) as e:
+        pkg.phase1_cli.combine_file(str(lst), str(tmp_path / "combined"), prm0)
+    assert e.value.code == -9 and "r0" in str(e.value)
+    assert not os.path.exists(tmp_path / "combined")
+    with pytest.raises(pkg.PtauError) as e:
+        pkg.phase1_cli.transform_ratios_file(str(tmp_path / "missing"), 0, full)
+    assert e.value.code == -9
+    buf = bytes(full.accumulator_size)
+    with pytest.raises(pkg.PtauError) as e:
+        pkg.phase1_cli.transform_ratios_devices(buf, 0, full, [0, 0])
+    assert e.value.code == -1 and "twice" in str(e.value)
+    with pytest.raises(pkg.PtauError) as e:
+        pkg.phase1_cli.transform_ratios_devices(buf[:-1], 0, full, [0])
+    assert e.value.code == -2
+    t = pkg._lib.ptau_timing()
+    assert ctypes.sizeof(t) == 9 * 8 + 8 and hasattr(t, "ratio_checks") and hasattr(t, "pok_checks")
