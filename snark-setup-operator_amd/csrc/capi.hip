@@ -252,13 +252,13 @@ int run_apply_powers_dev(DeviceCtx *c, int curve, int group, const GroupOps *ops
     }
     const bool windowed = use_window_kernel();
     const uint64_t launch_cap = windowed
-        ? std::max<uint64_t>(256, std::min(MAX_LAUNCH_POINTS, MAX_WINDOW_TABLE_BYTES / (ptau::WINDOW_ENTRIES * ops->jac_bytes)))
+        ? std::max<uint64_t>(256, std::min(MAX_LAUNCH_POINTS, MAX_WINDOW_TABLE_BYTES / (ptau::WINDOW_ENTRIES * ops->wtab_entry_bytes)))
         : MAX_LAUNCH_POINTS;
     for (uint64_t off = 0; off < n; off += launch_cap) {
         const uint64_t m = std::min(launch_cap, n - off);
         int rc;
         if ((rc = grow(c->scratch, c->scratch_cap, m * ops->jac_bytes, err))) return rc;
-        if (windowed && (rc = grow(c->wtab, c->wtab_cap, m * ptau::WINDOW_ENTRIES * ops->jac_bytes, err))) return rc;
+        if (windowed && (rc = grow(c->wtab, c->wtab_cap, m * ptau::WINDOW_ENTRIES * ops->wtab_entry_bytes, err))) return rc;
         if ((rc = grow(c->pre, c->pre_cap, m * ops->fe_bytes, err))) return rc;
         ops->build_table(tau, coeff, start + off, table.data());
         HIP_TRY(hipMemcpyAsync(c->d_table, table.data(), table.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
@@ -471,7 +471,7 @@ int run_msm_naive_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, in
                       uint8_t *out_host, int cout, const Err &err) {
     const int isz = cin ? ops->comp : ops->uncomp, osz = cout ? ops->comp : ops->uncomp;
     const uint64_t launch_cap =
-        std::max<uint64_t>(256, std::min(MAX_LAUNCH_POINTS, MAX_WINDOW_TABLE_BYTES / (ptau::WINDOW_ENTRIES * ops->jac_bytes)));
+        std::max<uint64_t>(256, std::min(MAX_LAUNCH_POINTS, MAX_WINDOW_TABLE_BYTES / (ptau::WINDOW_ENTRIES * ops->wtab_entry_bytes)));
     int rc;
     const uint64_t nlaunch = n ? (n + launch_cap - 1) / launch_cap : 1;
     // partial sums: one Jacobian per launch, kept at the tail of the scratch area
@@ -486,7 +486,7 @@ int run_msm_naive_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, in
     uint64_t li = 0;
     for (uint64_t off = 0; off < n; off += launch_cap, li++) {
         const uint64_t m = std::min(launch_cap, n - off);
-        if ((rc = grow(c->wtab, c->wtab_cap, m * ptau::WINDOW_ENTRIES * ops->jac_bytes, err))) return rc;
+        if ((rc = grow(c->wtab, c->wtab_cap, m * ptau::WINDOW_ENTRIES * ops->wtab_entry_bytes, err))) return rc;
         ptau::ScalarSource s2 = src;
         if (s2.mode == ptau::SCALAR_ARRAY) s2.ptr += off * ops->fr_limbs32;
         s2.index_base += off;
@@ -551,7 +551,7 @@ int enqueue_subgroup_kernels(DeviceCtx *c, int curve, int group, const GroupOps 
                              const Err &err) {
     const int isz = cin ? ops->comp : ops->uncomp;
     const uint64_t launch_cap =
-        std::max<uint64_t>(256, std::min(MAX_LAUNCH_POINTS, MAX_WINDOW_TABLE_BYTES / (ptau::WINDOW_ENTRIES * ops->jac_bytes)));
+        std::max<uint64_t>(256, std::min(MAX_LAUNCH_POINTS, MAX_WINDOW_TABLE_BYTES / (ptau::WINDOW_ENTRIES * ops->wtab_entry_bytes)));
     const bool via_psi = ops->psi_check && use_endo_subgroup();   // MNT twists: psi(P) == [t - 1]P, a half-length fixed scalar
     HIP_TRY(hipMemcpyAsync(c->d_table, via_psi ? ops->psi_scalar : ops->group_order, sizeof(uint32_t) * ops->fr_limbs32,
                            hipMemcpyHostToDevice, c->stream));
@@ -566,7 +566,7 @@ int enqueue_subgroup_kernels(DeviceCtx *c, int curve, int group, const GroupOps 
             const uint64_t m = std::min(launch_cap, n - off);
             int rc;
             if ((rc = grow(c->scratch, c->scratch_cap, m * ops->jac_bytes, err))) return rc;
-            if ((rc = grow(c->wtab, c->wtab_cap, m * ptau::WINDOW_ENTRIES * ops->jac_bytes, err))) return rc;
+            if ((rc = grow(c->wtab, c->wtab_cap, m * ptau::WINDOW_ENTRIES * ops->wtab_entry_bytes, err))) return rc;
             if (ops->subgroup_via_glv && use_endo_subgroup())   // [a]P + [b]phi(P) == O, |a|, |b| ~ sqrt(r): half the doublings, exact
                 ops->window_scalar_mul(c->stream, d_in + off * isz, cin, c->scratch, c->wtab, m,
                                        ptau::ScalarSource{ptau::SCALAR_SUBGROUP_ENDO, nullptr, 0, 0, 0}, 0, /*use_glv=*/1, c->d_err);
@@ -679,7 +679,7 @@ int enqueue_single_side(DeviceCtx *c, int curve, int group, const GroupOps *ops,
                         bool want_subgroup, const Err &err) {
     uint8_t *b = c->s_buf;
     int *d_err = (int *)(b + SB_ERR);
-    if (SB_SCRATCH + 9 * ops->jac_bytes > 16384) return err.fail(PTAU_E_DEVICE, "side buffer too small");
+    if (SB_SCRATCH + ops->jac_bytes + 8 * ops->wtab_entry_bytes > 16384) return err.fail(PTAU_E_DEVICE, "side buffer too small");
     HIP_TRY(hipMemsetAsync(d_err, 0, sizeof(int), c->side_stream));
     HIP_TRY(hipMemcpyAsync(b + SB_IN, in, ops->comp, hipMemcpyHostToDevice, c->side_stream));
     const int nonzero = (check_output == PTAU_CHECK_ONLY_NON_ZERO || check_output == PTAU_CHECK_FULL) ? 1 : 0;

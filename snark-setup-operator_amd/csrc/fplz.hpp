@@ -18,15 +18,21 @@ namespace ptau {
 
 template <class P>
 struct FpLZ {
+    using Params = P;
     static constexpr int N = P::N;
     static constexpr int H = N / 2;
     static constexpr int LB = P::LB;
     static constexpr uint32_t MASK = (1u << LB) - 1u;
     using L29 = FpL<typename P::P29>;
     using F29 = typename L29::Full;
-    static_assert(LB == 28 && N % 2 == 0 && L29::H == H, "written for the same limb count as the reduced lane-split form");
-    static_assert(LB * N >= F29::Params::BITS + 15, "R must exceed 2^15 p");
-    static_assert(P::MOD[N - 1] >= 16, "the biased multiples of p (SubC) borrow up to 15 from p's top limb");
+    static_assert(LB == 28 && N % 2 == 0, "28-bit limbs, an even number of them (half per lane)");
+    static constexpr int SLACK = LB * N - F29::Params::BITS;   // R = 2^(28 N) >= 2^SLACK p
+    static_assert(SLACK >= 15, "R must exceed 2^15 p");
+    // A product (a b + m p) / R < a b / R + p comes back below 2p when a b < R p, i.e. V1 V2 <= 2^SLACK.  BW6-761 (28 limbs,
+    // 761 bits): 2^23; MNT4/MNT6-753 (28 limbs for 753 bits — the reduced form has 26 of 29 bits): 2^31, so values there
+    // practically never need reducing, only limbs need their carries propagated.
+    static constexpr long long VPROD = 1ll << (SLACK > 31 ? 30 : SLACK - 1);
+    static constexpr int VMAX = SLACK - 1 > 29 ? (1 << 29) : (1 << (SLACK - 1));
     static_assert(2 * H * 17 < 512, "a slot of the accumulator row would overflow 64 bits");
 
     PTAU_HD static bool hi_lane() { return lane_parity() != 0; }
@@ -34,7 +40,8 @@ struct FpLZ {
     template <int U, int V>
     struct E {
         static_assert(U >= 1 && U <= 15, "a limb would not fit 32 bits");
-        static_assert(V >= 1 && V <= (1 << 14), "the value would not stay below R");
+        static_assert(V >= 1 && V <= VMAX, "the value would not stay below R");
+        static constexpr int LIMB_BOUND = U, VALUE_BOUND = V;
         uint32_t l[H];
         template <int U2, int V2>
         PTAU_HD operator E<U2, V2>() const {
@@ -48,6 +55,23 @@ struct FpLZ {
     using Nrm = E<1, 2>;
 
     struct Limbs { uint32_t l[N]; };
+    // floor(K p / 2^(28 (N - 1))): the top limb of K p
+    static constexpr long long top_of(long long K) {
+        unsigned long long c = 0;
+        for (int i = 0; i < N - 1; i++) c = ((unsigned long long)K * P::MOD[i] + c) >> LB;
+        return (long long)((unsigned long long)K * P::MOD[N - 1] + c);
+    }
+    // The multiple K p that sub() adds before subtracting a value below V2 p whose limbs are below (UB - 1) 2^28 (+ a
+    // carry's worth): every limb of the biased form must dominate the subtrahend's.  Below the top that is the bias; the top
+    // limb of K p, less the UB borrowed from it, must reach the top limb of any value below V2 p.  When p's own top limb is
+    // >= 16 (BW6-761) K = V2 + 1 does; a modulus that leaves the top limb empty (753 bits in 28 limbs) needs K p to reach
+    // 2^(28 (N - 1)) (UB + 1) more: K = V2 + ~9 (UB + 1).
+    static constexpr int subc_k(int V2, int UB) {
+        if (P::MOD[N - 1] >= 16) return V2 + 1;
+        long long K = V2 + 1;
+        while (top_of(K) - UB < top_of(V2) + 1) K++;
+        return (int)K;
+    }
     // K p with every limb below the top raised by UB 2^28, borrowed from the next limb up (see FpZ::make_subc)
     static constexpr Limbs make_subc(int K, int UB) {
         Limbs r{};
@@ -79,31 +103,34 @@ struct FpLZ {
         return r;
     }
     template <int U1, int V1, int U2, int V2>
-    PTAU_HD static E<U1 + U2 + 2, V1 + V2 + 1> sub(const E<U1, V1> &a, const E<U2, V2> &b) {
+    PTAU_HD static E<U1 + U2 + 2, V1 + subc_k(V2, U2 + 1)> sub(const E<U1, V1> &a, const E<U2, V2> &b) {
         const bool hi = hi_lane();
-        E<U1 + U2 + 2, V1 + V2 + 1> r;
+        constexpr int K = subc_k(V2, U2 + 1);
+        E<U1 + U2 + 2, V1 + K> r;
 #pragma unroll
-        for (int i = 0; i < H; i++) r.l[i] = a.l[i] + (hi ? SubC<V2 + 1, U2 + 1>::v.l[H + i] : SubC<V2 + 1, U2 + 1>::v.l[i]) - b.l[i];
+        for (int i = 0; i < H; i++) r.l[i] = a.l[i] + (hi ? SubC<K, U2 + 1>::v.l[H + i] : SubC<K, U2 + 1>::v.l[i]) - b.l[i];
         return r;
     }
     template <int U, int V>
-    PTAU_HD static E<U + 2, V + 1> neg(const E<U, V> &a) {
+    PTAU_HD static E<U + 2, subc_k(V, U + 1)> neg(const E<U, V> &a) {
         const bool hi = hi_lane();
-        E<U + 2, V + 1> r;
+        constexpr int K = subc_k(V, U + 1);
+        E<U + 2, K> r;
 #pragma unroll
-        for (int i = 0; i < H; i++) r.l[i] = (hi ? SubC<V + 1, U + 1>::v.l[H + i] : SubC<V + 1, U + 1>::v.l[i]) - a.l[i];
+        for (int i = 0; i < H; i++) r.l[i] = (hi ? SubC<K, U + 1>::v.l[H + i] : SubC<K, U + 1>::v.l[i]) - a.l[i];
         return r;
     }
     template <int K, int U, int V>
     PTAU_HD static E<K * U, K * V> times(const E<U, V> &a) {
-        static_assert(K == 2 || K == 3 || K == 4 || K == 8, "small multiples used by the point formulas");
+        static_assert(K >= 2 && K <= 15, "small multiples used by the point formulas");
         E<K * U, K * V> r;
 #pragma unroll
         for (int i = 0; i < H; i++) {
             if constexpr (K == 2) r.l[i] = a.l[i] + a.l[i];
             else if constexpr (K == 3) r.l[i] = a.l[i] + a.l[i] + a.l[i];
             else if constexpr (K == 4) r.l[i] = a.l[i] << 2;
-            else r.l[i] = a.l[i] << 3;
+            else if constexpr (K == 8) r.l[i] = a.l[i] << 3;
+            else r.l[i] = a.l[i] * (uint32_t)K;   // 11, 13, ...: shift-and-add chains chosen by the compiler
         }
         return r;
     }
@@ -231,7 +258,7 @@ struct FpLZ {
     template <int U1, int V1, int U2, int V2>
     PTAU_HD static Nrm mul(const E<U1, V1> &a, const E<U2, V2> &b) {
         static_assert(U1 * U2 <= 16, "a slot of the product's row would overflow 64 bits: normalise an operand first");
-        static_assert(V1 * V2 <= (1 << 15), "the product would not come back below 2p");
+        static_assert((long long)V1 * V2 <= VPROD, "the product would not come back below 2p");
         Nrm r;
 #if defined(__HIP_DEVICE_COMPILE__)
         VecH x, y;
@@ -250,7 +277,7 @@ struct FpLZ {
     template <int U, int V>
     PTAU_HD static Nrm sqr(const E<U, V> &a) {
         static_assert(U * U <= 16 && U <= 7, "a slot of the square's row would overflow 64 bits: normalise the operand first");
-        static_assert(V * V <= (1 << 15), "the square would not come back below 2p");
+        static_assert((long long)V * V <= VPROD, "the square would not come back below 2p");
         Nrm r;
 #if defined(__HIP_DEVICE_COMPILE__)
         VecH x;

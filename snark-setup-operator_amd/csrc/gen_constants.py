@@ -24,6 +24,9 @@ RADIX29 = {"BlsFq", "Mnt4Fq", "Mnt6Fq", "Bw6Fq"}
 # (fpl.hpp); its single-lane kernels (verify path) use the same representation so both kinds of kernel exchange values limb for limb.
 RADIX29_LIMBS = {"Bw6Fq": 28}
 LAZY28 = {"BlsFq", "Bw6Fq"}      # base fields that also get a carry-free 28-bit twin (fpz.hpp; lane-split: fplz.hpp)
+# ... and the 753-bit fields of the MNT cycle: 28 limbs of 28 bits over a lane pair (two more than the 26 x 29-bit reduced form),
+# R = 2^784 >= 2^31 p — a != 0 curves: no common-Z table, Jacobian table entries, lazy_a.hpp
+LAZY28_WIDE = {"Mnt4Fq", "Mnt6Fq"}
 
 
 # The MNT twists' G2 generators are NOT here: ark-mnt4-753 / ark-mnt6-753's constants are not recoverable offline, so the
@@ -222,8 +225,10 @@ def main():
     # modulus needs, so that R = 2^(28 N) >= 2^15 p: sums and differences of a few elements stay valid operands of a product
     # (no carry chain, no conditional subtraction) and a product brings any such operand back below 2p.
     lazy_twins = []
-    for name, p in ((nm, fields[nm][0]) for nm in sorted(LAZY28)):
+    for name, p in ((nm, fields[nm][0]) for nm in sorted(LAZY28 | LAZY28_WIDE)):
         lb, n = 28, (p.bit_length() + 15 + 27) // 28
+        if name in LAZY28_WIDE:
+            assert n % 2 == 0 and n == 28
         Rz, R29 = 1 << (lb * n), fields[name + "R29"][2]
         assert Rz >= p << 15      # (BLS12-377: p = 1 mod 2^28, so m_i = -acc mod 2^28 and m_i p_0 is an addition)
         out.append("struct %sZ28 {" % name)
@@ -232,6 +237,7 @@ def main():
         out.append("  static constexpr uint32_t INV = 0x%08xu;" % ((-pow(p, -1, 1 << lb)) % (1 << lb)))
         out.append("  static constexpr uint32_t MOD[%d] = {%s};" % (n, limbs(p, n, lb)))
         out.append("  static constexpr uint32_t R1[%d] = {%s};" % (n, limbs(Rz % p, n, lb)))
+        out.append("  static constexpr uint32_t R2[%d] = {%s};   // Rz^2 mod p: canonical -> Montgomery by one product" % (n, limbs(Rz * Rz % p, n, lb)))
         out.append("  static constexpr uint32_t FROM29[%d] = {%s};   // Rz^2 / R29 mod p: (x R29) -> (x Rz) by one product" % (n, limbs(Rz * Rz * pow(R29, -1, p) % p, n, lb)))
         out.append("  static constexpr uint32_t TO29[%d] = {%s};     // R29 mod p: (x Rz) -> (x R29)" % (n, limbs(R29 % p, n, lb)))
         out.append("  using P29 = %sR29;" % name)

@@ -1,0 +1,201 @@
+// K1 for the a != 0 curves (MNT4-753 / MNT6-753, both groups) in the carry-free field with one lane pair per tower
+// coefficient (lazy_a.hpp): reads uncompressed points, builds the per-point window table 1P..8P (Jacobian entries, 3 x 14
+// limbs per lane), runs the signed 4-bit window multiplication and leaves the Jacobian result in the STANDARD layout that
+// normalize_kernel of the single-lane group type reads (X.c0 X.c1 .. Y.c0 .. Z.c0 .., 26 limbs of 29 bits each, Montgomery).
+// Replaces setup-utils' batch_exp for these groups — /root/reference/src/bin/contribute.rs:811-823 — and, with a fixed
+// scalar, the multiplications of the membership tests (check_subgroup, contribute.rs:140-145).
+// Included by kernels_impl.hpp (ScalarSource, thread_scalar, WINDOW_*, ERRBIT_* live there).
+#pragma once
+#include "lazy_a.hpp"
+
+namespace ptau {
+
+template <class FqP, class FrP, class Cfg>
+struct LazyAGroup {
+    using P28 = typename LazyTwin<FqP>::type;
+    using Z = FpLZ<P28>;
+    static constexpr int DEG = Cfg::DEG;
+    using K = std::conditional_t<DEG == 1, Fp1PZ<Z>, std::conditional_t<DEG == 2, Fp2QZ<Z, Cfg::NR>, Fp3HZ<Z, Cfg::NR>>>;
+    static constexpr int LPP = 2 * DEG;                      // lanes per point
+    // value bound of the coordinates between point operations (the formulas are closed under it: checked by the compiler)
+    static constexpr int VC = DEG == 1 ? 512 : (DEG == 2 ? 3072 : 1024);
+    using Acc = LazyJacA<K, Cfg, VC>;
+    using CT = typename Acc::CT;
+    using Fr = Fp<FrP>;
+    using L29 = FpL<FqP>;                                    // a reduced coefficient over the pair: byte I/O, result store
+    static constexpr int N29 = FqP::N, H29 = N29 / 2;
+    static constexpr int H = Z::H;
+    static constexpr int COEF_BYTES = FqP::BYTES;
+    static constexpr int COMP = DEG * COEF_BYTES, UNCOMP = 2 * COMP;
+    static constexpr int ENTRY_WORDS = 3 * H;                // one table entry of one lane: X | Y | Z
+    static constexpr size_t WTAB_ENTRY_BYTES = (size_t)LPP * ENTRY_WORDS * 4;   // one table entry of one point
+    static constexpr int POINTS_PER_BLOCK = DEG == 3 ? 4 * 10 : 256 / LPP;
+};
+
+// One base-field coefficient from its canonical little-endian bytes straight into the carry-free Montgomery form of the
+// lane pair: both lanes read the bytes, test value < p on the packed words, cut their own 14 limbs of 28 bits and multiply by
+// Rz^2 (one lane-split product).  flags: the top two bits of the last byte when with_flags.
+template <class LG>
+__device__ inline bool lazy_a_read_coeff(const uint8_t *in, bool with_flags, uint8_t *flags, typename LG::Z::Nrm &out) {
+    using Z = typename LG::Z;
+    using P29 = typename LG::L29::Params;
+    constexpr int N32 = P29::N32, BYTES = P29::BYTES, H = Z::H, LB = Z::LB;
+    uint32_t w[N32 + 1];
+#pragma unroll
+    for (int t = 0; t <= N32; t++) w[t] = 0;
+    for (int t = 0; t < BYTES; t++) {
+        uint32_t byte = in[t];
+        if (t == BYTES - 1 && with_flags) {
+            *flags = (uint8_t)(byte & 0xC0u);
+            byte &= 0x3Fu;
+        }
+        w[t >> 2] |= byte << (8 * (t & 3));
+    }
+    uint32_t br = 0;
+#pragma unroll
+    for (int t = 0; t < N32; t++) (void)subb(w[t], P29::MOD32[t], br);
+    const bool hi = lane_parity() != 0;
+    typename Z::template E<1, 1> c, r2;
+#pragma unroll
+    for (int t = 0; t < H; t++) {
+        uint32_t half[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int bit = LB * (h * H + t), s = bit >> 5, o = bit & 31;
+            uint32_t v = s < N32 ? w[s] >> o : 0u;
+            if (o + LB > 32 && s + 1 < N32) v |= w[s + 1] << (32 - o);
+            half[h] = v & Z::MASK;
+        }
+        c.l[t] = hi ? half[1] : half[0];
+        r2.l[t] = Z::mine(Z::Params::R2, t);
+    }
+    out = Z::mul(c, r2);
+    return br != 0;   // value < p
+}
+
+// point index of this thread; false for idle lanes (lanes 60-63 of a wave in the 6-lane layout) and past the end
+template <class LG>
+__device__ inline bool lazy_a_point(uint64_t n, uint64_t &i) {
+    if constexpr (LG::DEG == 3) {
+        const uint32_t lane = threadIdx.x & 63u, g = (lane * 43u) >> 8;
+        if (g >= 10u) return false;
+        i = ((uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6)) * 10u + g;
+    } else {
+        i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / LG::LPP;
+    }
+    return i < n;
+}
+
+template <class LG>
+__device__ inline int window_scalar_mul_lazy_a_thread(const uint8_t *__restrict__ in, uint32_t *__restrict__ scratch,
+                                                      uint32_t *__restrict__ wtab, uint64_t n, uint64_t i, const ScalarSource &src,
+                                                      int check_input) {
+    using K = typename LG::K;
+    using Z = typename LG::Z;
+    using Acc = typename LG::Acc;
+    using CT = typename LG::CT;
+    using L29 = typename LG::L29;
+    using Fr = typename LG::Fr;
+    constexpr int D = LG::DEG, H = LG::H, NL = Fr::N, NW = NL * 8;
+    static_assert(Fr::Params::BITS <= 32 * NL - 3, "scalar field leaves no headroom for the digit offset");
+    const uint32_t j = K::coef(), hi = lane_parity();
+    // result slot of this lane in the standard Jacobian layout: coordinate c, coefficient j, limbs [hi H29, hi H29 + H29)
+    uint32_t *res = scratch + i * (uint64_t)(3 * D * LG::N29) + j * LG::N29 + hi * LG::H29;
+    auto put29 = [&](const L29 &v, int coord) {
+#pragma unroll
+        for (int t = 0; t < LG::H29; t++) res[coord * D * LG::N29 + t] = v.l[t];
+    };
+    // ---- the point: this pair's coefficient of x and of y (flags sit in the last byte of y's LAST coefficient) ----
+    const uint8_t *pp = in + i * LG::UNCOMP;
+    uint8_t fl = 0, dummy = 0;
+    typename Z::Nrm xz, yz;
+    bool ok = lazy_a_read_coeff<LG>(pp + j * LG::COEF_BYTES, false, &dummy, xz);
+    ok &= lazy_a_read_coeff<LG>(pp + LG::COMP + j * LG::COEF_BYTES, j == (uint32_t)(D - 1), &fl, yz);
+    ok = K::all_lanes(ok);
+    const uint32_t flags = K::from_last((uint32_t)fl);
+    const bool inf = (flags & FLAG_INF) != 0;
+    int bad = ok ? 0 : ERRBIT_NONCANONICAL;
+    if ((check_input & 1) && inf) bad |= ERRBIT_INFINITY;
+    if (bad || inf) {   // uniform over the point's lanes
+        L29 one = L29::one(), zero = L29::zero();
+        if (j != 0u) one = zero;
+        put29(one, 0);
+        put29(one, 1);
+        put29(zero, 2);
+        return bad;
+    }
+    const CT px = K::wrap(xz), py = K::wrap(yz), pz = K::one();
+    // ---- table: entry e = (e + 1) P, this lane's 3 x H limbs contiguous; a multiple that is O is marked by Z = 0 limbs ----
+    const uint64_t nslots = n * LG::LPP, slot = i * LG::LPP + K::lane_in_point();
+    auto entry = [&](int e) { return wtab + ((uint64_t)e * nslots + slot) * LG::ENTRY_WORDS; };
+    auto store_entry = [&](int e, const Acc &q) {
+        uint32_t *w = entry(e);
+        const bool qinf = q.is_inf();
+#pragma unroll
+        for (int t = 0; t < H; t++) {
+            w[t] = K::raw(q.X).l[t];
+            w[H + t] = K::raw(q.Y).l[t];
+            w[2 * H + t] = qinf ? 0u : K::raw(q.Zc).l[t];
+        }
+    };
+    {
+        Acc cur = {px, py, pz};
+        store_entry(0, cur);
+#pragma nounroll
+        for (int e = 1; e < WINDOW_ENTRIES; e++) {
+            cur = Acc::add(cur, px, py, pz);
+            store_entry(e, cur);
+        }
+    }
+    // ---- signed 4-bit windows, MSB first ----
+    uint32_t k[NL];
+    thread_scalar<Fr>(src, i, k);
+    uint32_t cy = 0;
+#pragma unroll
+    for (int t = 0; t < NL; t++) k[t] = addc(k[t], 0x88888888u, cy);
+    Acc acc = Acc::infinity();
+    for (int w = NW - 1; w >= 0; w--) {
+        if (!acc.is_inf()) {
+#pragma nounroll
+            for (int d = 0; d < WINDOW_BITS; d++) acc = Acc::dbl(acc);
+        }
+        uint32_t limb = 0;
+#pragma unroll
+        for (int t = 0; t < NL; t++) limb = (t == (w >> 3)) ? k[t] : limb;   // register select, no scratch
+        const int dgt = (int)((limb >> ((w & 7) * 4)) & 15u) - 8;
+        if (dgt != 0) {
+            const int mag = dgt < 0 ? -dgt : dgt;
+            const uint32_t *e = entry(mag - 1);
+            CT ex, ey, ez;
+#pragma unroll
+            for (int t = 0; t < H; t++) {
+                K::raw(ex).l[t] = e[t];
+                K::raw(ey).l[t] = e[H + t];
+                K::raw(ez).l[t] = e[2 * H + t];
+            }
+            if (!K::limbs_all_zero(ez)) {   // the multiple is not O
+                const auto ny = K::neg(ey);
+                decltype(K::neg(ey)) ys = ey;
+                if (dgt < 0) ys = ny;
+                acc = Acc::add(acc, ex, ys, ez);
+            }
+        }
+    }
+    // ---- back to the reduced field, standard layout ----
+    put29(Z::to29(K::raw(acc.X)), 0);
+    put29(Z::to29(K::raw(acc.Y)), 1);
+    put29(Z::to29(K::raw(acc.Zc)), 2);
+    return 0;
+}
+
+template <class LG>
+__global__ void __launch_bounds__(256, 2)
+window_scalar_mul_lazy_a_kernel(const uint8_t *__restrict__ in, uint32_t *__restrict__ scratch, uint32_t *__restrict__ wtab,
+                                uint64_t n, ScalarSource src, int check_input, int *__restrict__ err) {
+    uint64_t i;
+    if (!lazy_a_point<LG>(n, i)) return;
+    const int bad = window_scalar_mul_lazy_a_thread<LG>(in, scratch, wtab, n, i, src, check_input);
+    if (bad) atomicOr(err, bad);
+}
+
+}  // namespace ptau

@@ -17,6 +17,7 @@
 // The per-thread bodies are host+device so that tests/native/host_emul.hip can run the SAME code on the CPU against the
 // oracle (test infrastructure only: the product has no CPU path).
 #pragma once
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -1459,11 +1460,16 @@ decompress_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, uin
     if (bad) atomicOr(err, bad);
 }
 
+}  // namespace ptau
+#include "k1_lazy_a.hpp"
+namespace ptau {
+
 // ---------------------------------------------------------------------------------------------
 // Host-side launchers, one table per (curve, group); capi.hip dispatches through these.
 struct GroupOps {
     int comp, uncomp;          // serialized sizes
     size_t jac_bytes, fe_bytes;
+    size_t wtab_entry_bytes;   // one window-table entry of one point in K1 (>= jac_bytes: the widest kernel's layout)
     int fr_limbs32, fr_bits;
     // builds the device scalar table on the host: [base, tau^(2^k)...] Montgomery 32-bit limbs
     void (*build_table)(const uint64_t *tau, const uint64_t *coeff, uint64_t start, uint32_t *out);
@@ -1518,7 +1524,17 @@ constexpr bool twin_is() {
     if constexpr (std::is_void_v<GL>) return false;
     else return GL::LANE_MODE == MODE;
 }
-template <class G, class GL = void>
+// PTAU_LAZY_A=0 keeps the a != 0 groups on the round-2 kernels (reduced field, pair layout): A/B runs.
+inline bool lazy_a_enabled() {
+    static const bool v = [] {
+        const char *e = getenv("PTAU_LAZY_A");
+        return !(e && e[0] == '0');
+    }();
+    return v;
+}
+
+// GA: the carry-free one-pair-per-coefficient K1 of an a != 0 group (LazyAGroup, k1_lazy_a.hpp) or void.
+template <class G, class GL = void, class GA = void>
 struct Launch {
     using Fr = typename G::Fr;
     static dim3 grid(uint64_t n) { return dim3((unsigned)((n + 255) / 256)); }
@@ -1554,6 +1570,15 @@ struct Launch {
     static void window_scalar_mul(hipStream_t s, const uint8_t *in, int cin, void *scratch, void *wtab, uint64_t n,
                                   ScalarSource src, int check_input, int use_glv, int *err) {
         if (!n) return;
+        if constexpr (!std::is_void_v<GA>) {
+            static_assert(GA::UNCOMP == G::UNCOMP && 3 * GA::DEG * GA::N29 * 4 == sizeof(typename G::J), "standard layouts");
+            if (!cin && lazy_a_enabled()) {   // 2 / 4 / 6 lanes per point; results land in G's Jacobian layout
+                const uint64_t blocks = (n + GA::POINTS_PER_BLOCK - 1) / GA::POINTS_PER_BLOCK;
+                hipLaunchKernelGGL(window_scalar_mul_lazy_a_kernel<GA>, dim3((unsigned)blocks), dim3(256), 0, s, in, (uint32_t *)scratch,
+                                   (uint32_t *)wtab, n, src, check_input, err);
+                return;
+            }
+        }
         if constexpr (!std::is_void_v<GL>) {
             if (!cin && lane_pair_enabled()) {   // two threads per point; results land in G's Jacobian layout
                 hipLaunchKernelGGL((window_scalar_mul_kernel<GL, 0>), grid(n * 2), dim3(256), 0, s, in, (typename GL::J *)scratch,
@@ -1662,6 +1687,8 @@ struct Launch {
         o.uncomp = G::UNCOMP;
         o.jac_bytes = sizeof(typename G::J);
         o.fe_bytes = sizeof(typename G::F);
+        o.wtab_entry_bytes = sizeof(typename G::J);
+        if constexpr (!std::is_void_v<GA>) o.wtab_entry_bytes = std::max(o.wtab_entry_bytes, (size_t)GA::WTAB_ENTRY_BYTES);
         o.fr_limbs32 = Fr::N;
         o.fr_bits = Fr::Params::BITS;
         o.build_table = build_table;

@@ -1,0 +1,422 @@
+// Carry-free arithmetic for the a != 0 curves (MNT4-753 / MNT6-753) with EVERY tower coefficient on its own lane pair:
+//   G1          : Fq      = FpLZ<P28>              2 lanes per point (the element's limbs split over the pair, fplz.hpp)
+//   G2 (MNT4)   : Fq2     = Fp2QZ<FpLZ, 13>        4 lanes per point — pair 0 holds c0, pair 1 holds c1
+//   G2 (MNT6)   : Fq3     = Fp3HZ<FpLZ, 11>        6 lanes per point — pair j holds c_j, ten points per wavefront
+// A Jacobian point is then 3 x 14 VGPRs per lane whatever the extension degree, every point operation is inlined around
+// register-ABI base products (FpLZ::mul_vec / sqr_vec) and NOTHING of the window loop goes through memory — the round-2
+// kernels ran Fq2 / Fq3 point operations out of line by reference (3.4-5.6 KB of scratch per lane, 11 000-20 000 x the
+// algorithmic bytes through the L2, 35-39 % of wave cycles waiting: profiles/r02_pmc_cfg4.json).
+// Spreading costs multiply-accumulates (schoolbook 4 / 9 base products where Karatsuba needs 3 / 6) but a square stays at
+// 2 / 6 and squares dominate the doubling (1M + 8S), and the sums, differences and non-residue multiples of the tower —
+// ~230-instruction cross-lane carry chains each in the reduced field — become 14 limb-wise instructions.
+//
+// Field: 28 limbs of 28 bits, R = 2^784 >= 2^31 p (two limbs more than the reduced 26 x 29-bit form): values grow by
+// small factors through sums and differences and never need reducing before they meet a product again (V1 V2 <= 2^30);
+// only LIMBS need their carries propagated (`norm`) when a bound would overflow — all of it checked at compile time through
+// the E<U, V> types, as in fpz.hpp / fplz.hpp.
+//
+// Cross-lane moves: partner coefficients of a quad by DPP quad_perm; of a 6-lane group by ds_bpermute (no LDS memory is
+// touched: the crossbar only).  Every lane of a point executes the same instruction stream; data-dependent branches are
+// uniform over the point's lanes by construction (is_zero combines them).
+// Serves setup-utils' batch_exp on the MNT curves — /root/reference/src/bin/contribute.rs:811-823.  Device only.
+#pragma once
+#include "fplz.hpp"
+
+namespace ptau {
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PTAU_DPP(v, ctrl) ((uint32_t)__builtin_amdgcn_mov_dpp((int)(v), (ctrl), 0xF, 0xF, true))
+#else
+#define PTAU_DPP(v, ctrl) (v)
+#endif
+
+// ---- Fq2 = Fq[u] / (u^2 - NR) over a QUAD: lanes 0-1 hold c0 (low / high limbs), lanes 2-3 hold c1 ----
+template <class Z, int NR>
+struct Fp2QZ {
+    static_assert(NR >= 2 && NR <= 14, "non-residue multiples are formed limb-wise");
+    static constexpr int H = Z::H;
+    static constexpr int DEG = 2;
+    static constexpr int LANES = 4;
+    using Base = Z;
+    template <int U, int V>
+    struct E {
+        typename Z::template E<U, V> c;   // this lane pair's coefficient (this lane's half of its limbs)
+        template <int U2, int V2>
+        PTAU_HD operator E<U2, V2>() const { return {c}; }
+    };
+    static constexpr int PV = 2 + 2 * NR;        // a product's value bound: t1 + NR t2
+    static constexpr int SV = 2 + 2 * (Z::subc_k(14, 8));   // a square's: see sqr()
+    using Prod = E<1, PV>;
+
+    PTAU_HD static uint32_t coef() {   // which coefficient this lane's pair holds
+#if defined(__HIP_DEVICE_COMPILE__)
+        return (threadIdx.x >> 1) & 1u;
+#else
+        return 0;
+#endif
+    }
+    PTAU_HD static uint32_t lane_in_point() {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return threadIdx.x & 3u;
+#else
+        return 0;
+#endif
+    }
+    template <class T>
+    PTAU_HD static T other(const T &v) {   // the other pair's coefficient: quad_perm [2,3,0,1]
+        T r;
+#pragma unroll
+        for (int i = 0; i < H; i++) r.l[i] = PTAU_DPP(v.l[i], 0x4E);
+        return r;
+    }
+    template <class T>
+    PTAU_HD static T from_c0(const T &v) {   // quad_perm [0,1,0,1]
+        T r;
+#pragma unroll
+        for (int i = 0; i < H; i++) r.l[i] = PTAU_DPP(v.l[i], 0x44);
+        return r;
+    }
+    template <class T>
+    PTAU_HD static T from_c1(const T &v) {   // quad_perm [2,3,2,3]
+        T r;
+#pragma unroll
+        for (int i = 0; i < H; i++) r.l[i] = PTAU_DPP(v.l[i], 0xEE);
+        return r;
+    }
+    PTAU_HD static bool all4(bool mine) {   // `mine` is already uniform over the pair
+        const uint32_t theirs = PTAU_DPP(mine ? 1u : 0u, 0x4E);
+        return mine && theirs != 0u;
+    }
+
+    template <int U1, int V1, int U2, int V2>
+    PTAU_HD static E<U1 + U2, V1 + V2> add(const E<U1, V1> &a, const E<U2, V2> &b) { return {Z::add(a.c, b.c)}; }
+    template <int U1, int V1, int U2, int V2>
+    PTAU_HD static auto sub(const E<U1, V1> &a, const E<U2, V2> &b) {
+        const auto r = Z::sub(a.c, b.c);
+        return E<decltype(r)::LIMB_BOUND, decltype(r)::VALUE_BOUND>{r};
+    }
+    template <int U, int V>
+    PTAU_HD static auto neg(const E<U, V> &a) {
+        const auto r = Z::neg(a.c);
+        return E<decltype(r)::LIMB_BOUND, decltype(r)::VALUE_BOUND>{r};
+    }
+    template <int K, int U, int V>
+    PTAU_HD static E<K * U, K * V> times(const E<U, V> &a) { return {Z::template times<K>(a.c)}; }
+    template <int U, int V>
+    PTAU_HD static E<1, V> norm(const E<U, V> &a) { return {Z::norm(a.c)}; }
+
+    // pair 0: a0 b0 + NR a1 b1      pair 1: a1 b0 + a0 b1          (two base products per pair)
+    template <int U1, int V1, int U2, int V2>
+    PTAU_HD static Prod mul(const E<U1, V1> &a, const E<U2, V2> &b) {
+        const uint32_t f = coef() ? 1u : (uint32_t)NR;
+        const auto t1 = Z::mul(a.c, from_c0(b.c));          // pair 0: a0 b0   pair 1: a1 b0
+        const auto t2 = Z::mul(other(a.c), from_c1(b.c));   // pair 0: a1 b1   pair 1: a0 b1
+        typename Z::template E<1 + NR, PV> r;
+#pragma unroll
+        for (int i = 0; i < H; i++) r.l[i] = t1.l[i] + t2.l[i] * f;
+        return {Z::norm(r)};
+    }
+    // complex squaring, ONE base product per pair:  pair 0: (a0 + a1)(a0 + NR a1) - (1 + NR) a0 a1     pair 1: 2 a0 a1
+    template <int U, int V>
+    PTAU_HD static E<1, SV> sqr(const E<U, V> &a_in) {
+        static_assert((1 + NR) % 2 == 0 && (1 + NR) / 2 <= 7, "the correction (1 + NR) a0 a1 is subtracted in two halves");
+        const auto a = Z::norm(a_in.c);
+        const uint32_t m0 = coef() ? 0u : 0xffffffffu;      // all ones in the pair that holds c0
+        const auto ot = other(a);
+        const auto nr = Z::template times<NR>(ot);
+        typename Z::template E<2, 2 * V> l;
+        typename Z::template E<1 + NR, (1 + NR) * V> r;
+#pragma unroll
+        for (int i = 0; i < H; i++) {
+            l.l[i] = ot.l[i] + (a.l[i] & m0);                // pair 0: a0 + a1        pair 1: a0
+            r.l[i] = a.l[i] + (nr.l[i] & m0);                // pair 0: a0 + NR a1     pair 1: a1
+        }
+        const auto t = Z::mul(l, Z::norm(r));                // pair 0: (a0 + a1)(a0 + NR a1)     pair 1: a0 a1
+        const auto v = from_c1(t);
+        constexpr int HK = (1 + NR) / 2;
+        const auto hv = Z::template times<HK>(v);
+        const auto d1 = Z::norm(Z::sub(t, hv));
+        const auto d2 = Z::sub(d1, hv);                       // t - (1 + NR) a0 a1 + a multiple of p
+        typename Z::template E<decltype(d2)::LIMB_BOUND, decltype(d2)::VALUE_BOUND> o;
+#pragma unroll
+        for (int i = 0; i < H; i++) o.l[i] = m0 ? d2.l[i] : t.l[i] + t.l[i];
+        static_assert(decltype(d2)::VALUE_BOUND <= SV, "square bound");
+        return {Z::norm(o)};
+    }
+    // a * v for the twist coefficient a = A_SMALL in the base field
+    template <int A, int V>
+    PTAU_HD static auto mul_by_a(const E<1, V> &x) {
+        static_assert(A == 26, "MNT4-753 twist: a = 2 * 13");
+        return times<2>(norm(times<13>(x)));
+    }
+    PTAU_HD static E<1, 2> zero() { return {Z::zero()}; }
+    PTAU_HD static E<1, 2> one() {
+        const auto o = Z::one();
+        E<1, 2> r;
+        const uint32_t m0 = coef() ? 0u : 0xffffffffu;
+#pragma unroll
+        for (int i = 0; i < H; i++) r.c.l[i] = o.l[i] & m0;
+        return r;
+    }
+    template <int V>
+    PTAU_HD static bool is_zero(const E<1, V> &a) { return all4(Z::is_zero(a.c)); }
+    template <int U, int V>
+    PTAU_HD static bool limbs_all_zero(const E<U, V> &a) { return all4(Z::limbs_all_zero(a.c)); }
+    // plumbing for the kernels: this lane's limbs of an element, a base-field value as this pair's coefficient, a word of
+    // the LAST coefficient's pair in every lane, a predicate over the point's lanes
+    template <class T>
+    PTAU_HD static auto &raw(T &v) { return v.c; }
+    template <class T>
+    PTAU_HD static E<T::LIMB_BOUND, T::VALUE_BOUND> wrap(const T &z) { return {z}; }
+    PTAU_HD static uint32_t from_last(uint32_t v) { return PTAU_DPP(v, 0xEE); }
+    PTAU_HD static bool all_lanes(bool mine) { return all4(mine); }
+};
+
+// ---- Fq3 = Fq[u] / (u^3 - NR) over SIX lanes: pair j (lanes 2j, 2j + 1 of the group) holds c_j; groups of six lanes
+// from lane 0 of the wavefront, ten per wave64 (lanes 60-63 idle) ----
+template <class Z, int NR>
+struct Fp3HZ {
+    static_assert(NR >= 2 && NR <= 13, "non-residue multiples are formed limb-wise");
+    static constexpr int H = Z::H;
+    static constexpr int DEG = 3;
+    static constexpr int LANES = 6;
+    static constexpr int POINTS_PER_WAVE = 10;
+    using Base = Z;
+    template <int U, int V>
+    struct E {
+        typename Z::template E<U, V> c;
+        template <int U2, int V2>
+        PTAU_HD operator E<U2, V2>() const { return {c}; }
+    };
+    static constexpr int PV = 2 + 4 * NR;   // a product: t0 + NR t1 + NR t2
+    static constexpr int SV = 4 + 4 * NR;   // a square:  2 t0 + 2 NR t1
+    using Prod = E<1, PV>;
+
+    struct Pos { uint32_t lane, grp, j, base; };   // wave-local lane, group, coefficient, first lane of the group
+    PTAU_HD static Pos pos() {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uint32_t lane = threadIdx.x & 63u, g = (lane * 43u) >> 8;   // lane / 6 for lane < 64
+        return {lane, g, (lane - 6u * g) >> 1, 6u * g};
+#else
+        return {0, 0, 0, 0};
+#endif
+    }
+    PTAU_HD static uint32_t coef() { return pos().j; }
+    PTAU_HD static uint32_t lane_in_point() {
+        const Pos p = pos();
+        return p.lane - p.base;
+    }
+    PTAU_HD static uint32_t bperm(uint32_t src_lane, uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v);
+#else
+        (void)src_lane;
+        return v;
+#endif
+    }
+    // the coefficient held by pair (j + k) mod 3
+    template <class T>
+    PTAU_HD static T rot(const T &v, uint32_t k) {
+        const Pos p = pos();
+        uint32_t jj = p.j + k;
+        jj = jj >= 3u ? jj - 3u : jj;
+        const uint32_t src = p.base + 2u * jj + (p.lane & 1u);
+        T r;
+#pragma unroll
+        for (int i = 0; i < H; i++) r.l[i] = bperm(src, v.l[i]);
+        return r;
+    }
+    // coefficient k in every pair
+    template <class T>
+    PTAU_HD static T from_c(const T &v, uint32_t k) {
+        const Pos p = pos();
+        const uint32_t src = p.base + 2u * k + (p.lane & 1u);
+        T r;
+#pragma unroll
+        for (int i = 0; i < H; i++) r.l[i] = bperm(src, v.l[i]);
+        return r;
+    }
+    PTAU_HD static bool all6(bool mine) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const Pos p = pos();
+        const unsigned long long b = __ballot(mine ? 1 : 0);
+        return ((b >> p.base) & 0x3Full) == 0x3Full;
+#else
+        return mine;
+#endif
+    }
+
+    template <int U1, int V1, int U2, int V2>
+    PTAU_HD static E<U1 + U2, V1 + V2> add(const E<U1, V1> &a, const E<U2, V2> &b) { return {Z::add(a.c, b.c)}; }
+    template <int U1, int V1, int U2, int V2>
+    PTAU_HD static auto sub(const E<U1, V1> &a, const E<U2, V2> &b) {
+        const auto r = Z::sub(a.c, b.c);
+        return E<decltype(r)::LIMB_BOUND, decltype(r)::VALUE_BOUND>{r};
+    }
+    template <int U, int V>
+    PTAU_HD static auto neg(const E<U, V> &a) {
+        const auto r = Z::neg(a.c);
+        return E<decltype(r)::LIMB_BOUND, decltype(r)::VALUE_BOUND>{r};
+    }
+    template <int K, int U, int V>
+    PTAU_HD static E<K * U, K * V> times(const E<U, V> &a) { return {Z::template times<K>(a.c)}; }
+    template <int U, int V>
+    PTAU_HD static E<1, V> norm(const E<U, V> &a) { return {Z::norm(a.c)}; }
+
+    // r_j = sum_k a_{j-k} b_k, terms that wrap below u^0 times NR: round k multiplies pair j's a_{(j - k) mod 3} by b_k
+    template <int U1, int V1, int U2, int V2>
+    PTAU_HD static Prod mul(const E<U1, V1> &a, const E<U2, V2> &b) {
+        const uint32_t j = coef();
+        const uint32_t f1 = j < 1u ? (uint32_t)NR : 1u, f2 = j < 2u ? (uint32_t)NR : 1u;
+        const auto t0 = Z::mul(a.c, from_c(b.c, 0));
+        const auto t1 = Z::mul(rot(a.c, 2), from_c(b.c, 1));
+        typename Z::template E<1 + NR, 2 + 2 * NR> s1;
+#pragma unroll
+        for (int i = 0; i < H; i++) s1.l[i] = t0.l[i] + t1.l[i] * f1;
+        const auto n1 = Z::norm(s1);
+        const auto t2 = Z::mul(rot(a.c, 1), from_c(b.c, 2));
+        typename Z::template E<1 + NR, PV> s2;
+#pragma unroll
+        for (int i = 0; i < H; i++) s2.l[i] = n1.l[i] + t2.l[i] * f2;
+        return {Z::norm(s2)};
+    }
+    // r0 = a0^2 + 2 NR a1 a2,  r1 = 2 a0 a1 + NR a2^2,  r2 = 2 a0 a2 + a1^2: two base products per pair
+    template <int U, int V>
+    PTAU_HD static E<1, SV> sqr(const E<U, V> &a) {
+        const uint32_t j = coef();
+        const auto r1 = rot(a.c, 1), r2 = rot(a.c, 2);
+        const auto t0 = Z::mul(from_c(a.c, 0), a.c);          // a0^2 | a0 a1 | a0 a2
+        typename Z::template E<U, V> x, y;
+#pragma unroll
+        for (int i = 0; i < H; i++) {
+            x.l[i] = j == 2u ? r2.l[i] : r1.l[i];               // a1 | a2 | a1
+            y.l[i] = j == 1u ? r1.l[i] : r2.l[i];               // a2 | a2 | a1
+        }
+        const auto t1 = Z::mul(x, y);                          // a1 a2 | a2^2 | a1^2
+        const uint32_t f0 = j == 0u ? 1u : 2u, g1 = j == 2u ? 1u : (uint32_t)NR, g2 = j == 0u ? (uint32_t)NR : 0u;
+        typename Z::template E<2 + NR, 4 + 2 * NR> s1;
+#pragma unroll
+        for (int i = 0; i < H; i++) s1.l[i] = t0.l[i] * f0 + t1.l[i] * g1;
+        const auto n1 = Z::norm(s1);
+        typename Z::template E<1 + NR, SV> s2;
+#pragma unroll
+        for (int i = 0; i < H; i++) s2.l[i] = n1.l[i] + t1.l[i] * g2;
+        return {Z::norm(s2)};
+    }
+    // a * v for the twist coefficient a = A u^2:  (c0, c1, c2) u^2 = (NR c1, NR c2, c0)
+    template <int A, int V>
+    PTAU_HD static E<1, A * NR * V> mul_by_a(const E<1, V> &x) {
+        static_assert(A <= 15, "small twist coefficient");
+        const uint32_t f = coef() < 2u ? (uint32_t)NR : 1u;
+        const auto y = Z::norm(Z::template times<A>(rot(x.c, 1)));
+        typename Z::template E<NR, A * NR * V> s;
+#pragma unroll
+        for (int i = 0; i < H; i++) s.l[i] = y.l[i] * f;
+        return {Z::norm(s)};
+    }
+    PTAU_HD static E<1, 2> zero() { return {Z::zero()}; }
+    PTAU_HD static E<1, 2> one() {
+        const auto o = Z::one();
+        E<1, 2> r;
+        const uint32_t m0 = coef() ? 0u : 0xffffffffu;
+#pragma unroll
+        for (int i = 0; i < H; i++) r.c.l[i] = o.l[i] & m0;
+        return r;
+    }
+    template <int V>
+    PTAU_HD static bool is_zero(const E<1, V> &a) { return all6(Z::is_zero(a.c)); }
+    template <int U, int V>
+    PTAU_HD static bool limbs_all_zero(const E<U, V> &a) { return all6(Z::limbs_all_zero(a.c)); }
+    template <class T>
+    PTAU_HD static auto &raw(T &v) { return v.c; }
+    template <class T>
+    PTAU_HD static E<T::LIMB_BOUND, T::VALUE_BOUND> wrap(const T &z) { return {z}; }
+    PTAU_HD static uint32_t from_last(uint32_t v) {
+        const Pos p = pos();
+        return bperm(p.base + 4u + (p.lane & 1u), v);
+    }
+    PTAU_HD static bool all_lanes(bool mine) { return all6(mine); }
+};
+
+// The prime field seen through the same interface (G1): FpLZ itself plus the tower hooks.
+template <class Z>
+struct Fp1PZ : Z {
+    static constexpr int DEG = 1;
+    static constexpr int LANES = 2;
+    using Base = Z;
+    using Prod = typename Z::Nrm;
+    PTAU_HD static uint32_t coef() { return 0; }
+    PTAU_HD static uint32_t lane_in_point() { return lane_parity(); }
+    template <class T>
+    PTAU_HD static auto &raw(T &v) { return v; }
+    template <class T>
+    PTAU_HD static const T &wrap(const T &z) { return z; }
+    PTAU_HD static uint32_t from_last(uint32_t v) { return v; }
+    PTAU_HD static bool all_lanes(bool mine) { return Z::both(mine); }
+};
+
+// ---- Jacobian arithmetic on y^2 = x^3 + a x + b, a != 0, over one of the fields above -----------------------------------
+// Coordinates between operations: limbs normalised, values below VC p (the formulas below are closed under that bound —
+// the assignments to CT fail to compile otherwise).  Z = 0 mod p  <=>  the point at infinity.
+template <class K, class Cfg, int VC_>
+struct LazyJacA {
+    static constexpr int VC = VC_;
+    using CT = typename K::template E<1, VC>;
+    CT X, Y, Zc;
+
+    PTAU_HD static LazyJacA infinity() { return {K::one(), K::one(), K::zero()}; }
+    PTAU_HD bool is_inf() const { return K::is_zero(Zc); }
+
+    template <class T>
+    PTAU_HD static auto a_times(const T &zz2) {
+        if constexpr (K::DEG == 1) return K::template times<Cfg::A_SMALL>(zz2);
+        else return K::template mul_by_a<Cfg::A_SMALL>(zz2);
+    }
+
+    // dbl-2007-bl: 1M + 8S.  The point at infinity maps to itself (Z3 = 2 Y1 Z1).
+    PTAU_HD static LazyJacA dbl(const LazyJacA &p) {
+        const auto XX = K::sqr(p.X);
+        const auto YY = K::sqr(p.Y);
+        const auto YYYY = K::sqr(YY);
+        const auto ZZ = K::sqr(p.Zc);
+        const auto t = K::sqr(K::norm(K::add(p.X, YY)));
+        const auto S = K::norm(K::template times<2>(K::sub(t, K::add(XX, YYYY))));
+        const auto M = K::norm(K::add(K::template times<3>(XX), a_times(K::norm(K::sqr(ZZ)))));
+        LazyJacA r;
+        r.X = K::norm(K::sub(K::sqr(M), K::template times<2>(S)));
+        r.Y = K::norm(K::sub(K::mul(M, K::norm(K::sub(S, r.X))), K::template times<8>(YYYY)));
+        r.Zc = K::norm(K::sub(K::sqr(K::norm(K::add(p.Y, p.Zc))), K::add(YY, ZZ)));
+        return r;
+    }
+
+    // add-2007-bl: 11M + 5S; (x2, y2, z2) = a table entry (y2 possibly negated on the fly), never the point at infinity
+    template <class XT, class YT, class ZT>
+    PTAU_HD static LazyJacA add(const LazyJacA &p, const XT &x2, const YT &y2, const ZT &z2) {
+        const auto Z1Z1 = K::sqr(p.Zc);
+        const auto Z2Z2 = K::sqr(z2);
+        const auto U1 = K::mul(p.X, Z2Z2);
+        const auto U2 = K::mul(x2, Z1Z1);
+        const auto S1 = K::mul(K::mul(p.Y, z2), Z2Z2);
+        const auto S2 = K::mul(K::mul(K::norm(y2), p.Zc), Z1Z1);
+        const auto Hh = K::norm(K::sub(U2, U1));
+        const auto rh = K::norm(K::sub(S2, S1));
+        const auto I = K::sqr(K::template times<2>(Hh));
+        const auto J = K::mul(Hh, I);
+        const auto Vv = K::mul(U1, I);
+        const auto rr = K::template times<2>(rh);
+        LazyJacA r;
+        r.X = K::norm(K::sub(K::sqr(rr), K::add(J, K::template times<2>(Vv))));
+        r.Y = K::norm(K::sub(K::mul(rr, K::norm(K::sub(Vv, r.X))), K::template times<2>(K::mul(S1, J))));
+        r.Zc = K::mul(K::norm(K::sub(K::sqr(K::norm(K::add(p.Zc, z2))), K::add(Z1Z1, Z2Z2))), Hh);
+        // exceptional cases overwrite the generic result: one join, rare paths
+        const bool pinf = p.is_inf();
+        if (pinf || K::is_zero(Hh)) {
+            if (pinf) r = {x2, K::mul(K::norm(y2), K::one()), z2};   // y2 may carry a negation's bound: back below a product's
+            else if (K::is_zero(rh)) r = dbl(p);
+            else r = infinity();
+        }
+        return r;
+    }
+};
+
+}  // namespace ptau
