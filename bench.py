@@ -68,6 +68,8 @@ def cpu_baseline(curve, group, sample_points, chal_bytes, start, tau, single_cor
     from oracle import cref
     cores = usable_cores()
     cref.lib()
+    usz0 = len(chal_bytes) // sample_points
+    cref.apply_powers(curve, group, chal_bytes[:usz0], 1, start, tau, None, False, True, nthreads=1)   # one-time table set-up of the oracle: untimed
     t0 = time.time()
     out = cref.apply_powers(curve, group, chal_bytes, sample_points, start, tau, None, False, True, nthreads=cores)
     dt = time.time() - t0
@@ -83,6 +85,88 @@ def cpu_baseline(curve, group, sample_points, chal_bytes, start, tau, single_cor
             raise SystemExit("CPU oracle disagrees with itself across thread counts")
         res["single_core"] = {"value": m / d1, "sample": "%d points, 1 thread, %.1f s wall" % (m, d1)}
     return out, res
+
+
+def cpu_chunk_baseline(curve, log2_indices=14):
+    """CPU denominator of the stated target ("host-CPU chunk-contribution throughput"): Phase1::computation of the C oracle on
+    chunk 0 of a power-`log2_indices` ceremony — ALL FIVE vectors: per index one tauG1 + tauG2 + alphaG1 + betaG1 update (a
+    chunk index costs the same whatever the ceremony's power: the exponents are full-width) — on every usable core, and on ONE
+    core over a 16x smaller chunk.  Reported per chunk INDEX, and scaled to the whole chunk the GPU lines time."""
+    from oracle import cref
+    from oracle.pyref import phase1 as P
+    from oracle.pyref.curves import CURVES
+    cores = usable_cores()
+    cref.lib()
+    tau, alpha, beta = det_scalar("bench/tau") % (1 << 250), det_scalar("bench/alpha") % (1 << 250), det_scalar("bench/beta") % (1 << 250)
+    out = {"kind": "port", "cpu_model": cpu_model(), "cores": cores, "unit": "chunk indices/s (1 tauG1 + 1 tauG2 + 1 alphaG1 + 1 betaG1 update each)"}
+    warm = P.initialization(P.Params(CURVES[curve], P.CHUNKED, 0, 2, 1, 2))
+    cref.computation(curve, 0, 0, 2, 1, warm, tau, alpha, beta, nthreads=1)   # one-time table set-up of the oracle: untimed
+    for tag, lg, nt in (("all_cores", log2_indices, cores), ("single_core", max(6, log2_indices - 4), 1)):
+        n = 1 << lg
+        ch = P.initialization(P.Params(CURVES[curve], P.CHUNKED, 0, n, lg, n))
+        t0 = time.time()
+        cref.computation(curve, 0, 0, n, lg, ch, tau, alpha, beta, nthreads=nt)
+        dt = time.time() - t0
+        out[tag] = {"value": n / dt, "sample": "Phase1::computation (oracle/c) on chunk 0 of a 2^%d ceremony: %d G1 + %d G2 updates, %d threads, %.1f s wall"
+                                               % (lg, 3 * n, n + 1, nt, dt)}
+    out["value"] = out["all_cores"]["value"]
+    return out
+
+
+def cpu_verify_baseline(log2n=20):
+    """CPU denominator of "chunks verified/s" (--config 5): what the oracle spends per response element of a BLS12-377 chunk —
+    sqrt decompression, prime-order membership by [r]P (double-and-add) and its share of the random-linear-combination MSM
+    (bucket method, 127-bit coefficients as the GPU path draws them) — timed on bounded samples on every usable core
+    (slices on threads: the C calls release the GIL) and scaled to the 3 x 2^n G1 + 2^n G2 elements of chunk 0.  BLAKE2b and
+    the pairings are left out (they are host work in both implementations)."""
+    import random
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import cref
+    from oracle.pyref.curves import CURVES
+    curve, cores = "bls12_377", usable_cores()
+    cref.lib()
+    c = CURVES[curve]
+    rng = random.Random(7)
+    per_elem = {}
+    for group, sample in ((1, 1 << 12), (2, 1 << 10)):
+        nl = cref.fr_limbs(curve)
+        gen = cref.scalar_mul(curve, group, _generator_bytes(curve, group), 1, 1, nl, shared=True)
+        usz, csz = cref.point_size(curve, group, False), cref.point_size(curve, group, True)
+        # `sample` distinct subgroup points: k_i * G
+        pts = cref.scalar_mul(curve, group, gen * sample, sample, [rng.randrange(1, c.r) for _ in range(sample)], nl)
+        comp = cref.scalar_mul(curve, group, pts, sample, 1, nl, shared=True, compressed_out=True)
+        per = max(1, sample // cores)
+        slices = [(i, min(sample, i + per)) for i in range(0, sample, per)]
+        with ThreadPoolExecutor(max_workers=cores) as ex:
+            t0 = time.time()
+            dec = cref.decompress(curve, group, comp, sample, nthreads=cores)
+            t1 = time.time()
+            list(ex.map(lambda ab: cref.scalar_mul(curve, group, pts[ab[0] * usz:ab[1] * usz], ab[1] - ab[0], c.r, nl, shared=True), slices))
+            t2 = time.time()
+            rho = [rng.getrandbits(127) for _ in range(sample)]
+            list(ex.map(lambda ab: cref.msm(curve, group, pts[ab[0] * usz:ab[1] * usz], ab[1] - ab[0], rho[ab[0]:ab[1]], nl), slices))
+            t3 = time.time()
+        assert dec == pts
+        per_elem[group] = {"decompress_s": (t1 - t0) / sample, "subgroup_s": (t2 - t1) / sample, "msm_s": 2 * (t3 - t2) / sample,
+                           "sample": sample}
+    n = 1 << log2n
+    chunk_s = sum(per_elem[1][k] for k in ("decompress_s", "subgroup_s", "msm_s")) * 3 * n + \
+        sum(per_elem[2][k] for k in ("decompress_s", "subgroup_s", "msm_s")) * n
+    return {"value": 1.0 / chunk_s, "unit": "chunks verified/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "sample": "C oracle (oracle/c) on %d G1 + %d G2 elements, %d threads: per element sqrt decompression + [r]P membership + "
+                      "2 x MSM share (power_pairs sums the vector and its shift); scaled to 3 x 2^%d G1 + 2^%d G2 elements; BLAKE2b and "
+                      "pairings excluded" % (per_elem[1]["sample"], per_elem[2]["sample"], cores, log2n, log2n),
+            "seconds_per_element": {"g1": {k: v for k, v in per_elem[1].items() if k != "sample"},
+                                    "g2": {k: v for k, v in per_elem[2].items() if k != "sample"}},
+            "projected_chunk_seconds": chunk_s}
+
+
+def _generator_bytes(curve, group):
+    from oracle.pyref import serde
+    from oracle.pyref.curves import CURVES
+    from oracle.pyref.ec import Group
+    G = Group(CURVES[curve], group)
+    return serde.write_point(G, G.gen, False)
 
 
 def initial_challenge_file(pkg, curve, prm, path, hash_path):
@@ -234,63 +318,72 @@ MAC_PEAK = 32.7e12        # measured v_mad_u64_u32 issue peak, lane-MACs/s chip-
 
 
 def macs_per_update(curve, group, endo):
-    """32x32->64 multiply-accumulates of one prime-field G1-type update, from the formulas the kernel runs:
-    product 2 N^2, square N^2 + N (N + 1) / 2 (lane-split fields: 2 N^2 - H (H - 1), H = N / 2); doubling 2M + 5S (a = 0) or
-    3M + 6S (+ a small a * Z^4 chain); table of 8 multiples by 7 mixed additions (7M + 4S); signed 4-bit windows (15/16 of
-    the digits are non-zero); window additions: mixed (7M + 4S) on the common-Z table of the j = 0 curves (+ 51 products to
-    rescale the table), full (11M + 5S) on the MNT curves.  BLS12-377 G1: the loop's products have 14 limbs (fpz.hpp).
-    None for the extension-field groups (their base-product count depends on the lane mapping; not modelled)."""
-    if group != 1 and curve != "bw6":
-        return None
-    n = FIELD_LIMBS[curve]
-    m = 2 * n * n
-    sq = m - (n // 2) * (n // 2 - 1) if curve != "bls12_377" else n * n + n * (n + 1) // 2   # lane-split square: H (H - 1) / 2 fewer MACs per lane
-    a_zero = curve in ("bls12_377", "bw6")
-    dbl = 2 * m + 5 * sq if a_zero else 3 * m + 6 * sq
-    madd = 7 * m + 4 * sq
-    add = madd if a_zero else 11 * m + 5 * sq
-    rescale = 51 * m if a_zero else 0
+    """32x32->64 multiply-accumulates of ONE update (all lanes of the point together), from the formulas the kernels run
+    (DESIGN.md §4).  Base products, per point:
+      FpZ   (BLS12-377, 14 limbs of 28 bits, one lane per coefficient; p = 1 mod 2^28): product 378, square 287
+      FpLZ  (BW6-761 and the MNT fields: 28 limbs of 28 bits over a lane pair): product 2 N^2 = 1568, square 1568 - 2 * 91 = 1386,
+            fused k-term product (ONE reduction, FpLZ::row_mul_multi): 784 (k + 1)
+    Tower products: BLS12-377 Fq2 over a lane pair = 2 products per lane (schoolbook), square = 1 per lane (complex);
+    MNT4 Fq2 over a quad = one fused 2-term product per pair, square = one product per pair (complex);
+    MNT6 Fq3 over six lanes = one fused 3-term product per pair, square = one fused 2-term product per pair.
+    Point formulas: a = 0: doubling 2M + 5S, mixed addition on the common-Z table 8M + 3S (G2: 7M + 4S), table = 7 mixed
+    additions + ~50 products + 8 squares to rescale; a != 0 (MNT): doubling 1M + 8S, full addition 11M + 5S, table = 7 additions.
+    Signed 4-bit windows, 15/16 of the digits non-zero."""
     bits = SCALAR_BITS[curve]
-    if curve == "bls12_377":
-        # table and window loop run in the carry-free twin field (fpz.hpp): 14 limbs of 28 bits; mixed addition 8M + 3S
-        # (Z3 = 2 Z1 H); one more converting product for beta
-        mz, sqz = 2 * 14 * 14, 14 * 14 + 14 * 15 // 2
-        dblz, maddz = 2 * mz + 5 * sqz, 8 * mz + 3 * sqz
-        # table in the same field: 7 mixed additions, 7 + 7 * 5 + 3 products and 8 squares for the common denominator,
-        # 2 + 3 converting products (the point in, the result out)
-        table = 7 * maddz + 50 * mz + 8 * sqz
-        if endo:
-            return (4 * 32 - 4) * dblz + 2 * 32 * 15 // 16 * maddz + 32 * 15 // 16 * mz + mz + table
-        windows = (bits + 3 + 3) // 4
-        return (4 * windows - 4) * dblz + windows * 15 // 16 * maddz + table
-    if curve == "bw6":
-        # table and window loop run in the carry-free lane-split field (fplz.hpp): the same 28 limbs; mixed addition 8M + 3S;
-        # one more converting product for beta
-        maddz = 8 * m + 3 * sq
-        table = 7 * maddz + 50 * m + 8 * sq
-        if endo:
-            return (4 * 48 - 4) * dbl + 2 * 48 * 15 // 16 * maddz + 48 * 15 // 16 * m + m + table
-        windows = (bits + 3 + 3) // 4
-        return (4 * windows - 4) * dbl + windows * 15 // 16 * maddz + table
-    if endo and a_zero:
-        half = 128 if curve == "bls12_377" else 192
-        windows = half // 4
-        return (4 * windows - 4) * dbl + 2 * windows * 15 // 16 * add + windows * 15 // 16 * m + 7 * madd + rescale
     windows = (bits + 3 + 3) // 4
-    return (4 * windows - 4) * dbl + windows * 15 // 16 * add + 7 * madd + rescale
+    if curve == "bls12_377" and group == 1:
+        m, sq = 2 * 14 * 14, 14 * 14 + 14 * 15 // 2                 # 392 / 301 (the m_i p_0 terms counted: the model of rounds 1-2)
+        dbl, madd = 2 * m + 5 * sq, 8 * m + 3 * sq
+        table = 7 * madd + 50 * m + 8 * sq
+        if endo:
+            return (4 * 32 - 4) * dbl + 2 * 32 * 15 // 16 * madd + 32 * 15 // 16 * m + m + table
+        return (4 * windows - 4) * dbl + windows * 15 // 16 * madd + table
+    if curve == "bls12_377":      # G2: Fq2 over a lane pair, FpZ coefficients
+        b, bs = 2 * 14 * 14, 14 * 14 + 14 * 15 // 2
+        m, sq = 4 * b, 2 * b                                           # schoolbook product, complex square (products, not squares)
+        dbl, madd = 2 * m + 5 * sq, 7 * m + 4 * sq
+        table = 7 * madd + 50 * m + 8 * sq + 10 * 2 * b
+        if endo:      # GLS: 17 windows of four 64-bit sub-scalars, psi^j on 3 of 4 entries (two Fq2-by-Fq products)
+            return (4 * 17 - 4) * dbl + 4 * 17 * 15 // 16 * madd + 3 * 17 * 15 // 16 * 2 * 2 * b + table
+        return (4 * windows - 4) * dbl + windows * 15 // 16 * madd + table
+    m, sq = 2 * 28 * 28, 2 * 28 * 28 - 2 * 91
+    if curve == "bw6":
+        dbl, madd = 2 * m + 5 * sq, 8 * m + 3 * sq
+        table = 7 * madd + 50 * m + 8 * sq
+        if endo:
+            return (4 * 48 - 4) * dbl + 2 * 48 * 15 // 16 * madd + 48 * 15 // 16 * m + m + table
+        return (4 * windows - 4) * dbl + windows * 15 // 16 * madd + table
+    # MNT4 / MNT6 (k1_lazy_a.hpp): a != 0, Jacobian table entries, no endomorphism
+    fused = lambda k: 784 * (k + 1)
+    if group == 1:
+        M, S = m, sq
+    elif curve == "mnt4_753":
+        M, S = 2 * fused(2), 2 * m
+    else:
+        M, S = 3 * fused(3), 3 * fused(2)
+    dbl, add = M + 8 * S, 11 * M + 5 * S
+    io = 5 * m * (1 if group == 1 else (2 if curve == "mnt4_753" else 3))   # 2 converting products in, 3 out, per coefficient
+    return (4 * windows - 4) * dbl + (windows * 15 // 16 + 7) * add + io
 
 
-def pmc_for(tag):
-    """Counters of window_scalar_mul_kernel<tag> from the newest committed rocprofv3 PMC summary (profiles/)."""
+def pmc_for(tag, config):
+    """Counters of window_scalar_mul*kernel<tag> from the rocprofv3 PMC summary of THIS config and the NEWEST round that has one
+    (profiles/rNN_pmc_cfg<config>.json, written by tools/gpu_round.sh before the bench line is taken).  No fallback to
+    another config's file: a summary that lacks the kernel yields None."""
     import glob
+    import re
+    files = glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_cfg%d.json" % config))
+    env = os.environ.get("PTAU_BENCH_PMC")          # gpu_round.sh points at the summary it has just written
+    if env and os.path.exists(env):
+        files = [env]
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc*.json"))):
+    for f in sorted(files, key=lambda p: int(re.search(r"r(\d+)", os.path.basename(p)).group(1)) if re.search(r"r(\d+)", os.path.basename(p)) else -1):
         try:
             k = json.load(open(f)).get("kernels", {})
         except Exception:
             continue
         for name, d in k.items():
-            if name.startswith("window_scalar_mul_kernel") and ("<%s>" % tag) in name and "hbm_bytes_per_launch" in d:
+            if name.startswith("window_scalar_mul") and ("<%s>" % tag) in name and "hbm_bytes_per_launch" in d:
                 best = (d, os.path.basename(f))
     return best if best else (None, None)
 
@@ -527,12 +620,18 @@ def main():
         if got != ref:
             raise SystemExit("PARITY FAILURE: GPU response differs from the CPU oracle on the sampled points")
         tag = KERNEL_TAG[(curve, group)]
-        pmc, pmc_src = pmc_for(tag)
+        pmc, pmc_src = pmc_for(tag, args.config)
         traffic = pmc["hbm_bytes_per_launch"] if pmc else None
+        traffic_raw = pmc.get("hbm_bytes_per_launch_raw_fetch") if pmc else None
         macs = macs_per_update(curve, group, endo=False)
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": pmc_src,
                 "traffic_ratio": (traffic / (algo * n)) if traffic else None,
+                "traffic_raw_fetch": traffic_raw,
+                "traffic_note": "FETCH_SIZE x 2 + WRITE_SIZE (the guide's gfx950 correction holds for 16-B-per-lane streaming reads; "
+                                "this kernel's table reads are dword / dwordx2 per lane: traffic_raw_fetch = FETCH_SIZE + WRITE_SIZE is "
+                                "the uncorrected figure, tools/ubench_fetch.hip calibrates the two access patterns — "
+                                "profiles/r03_ubench_fetch.txt); Infinity-Cache hits are counted",
                 "algorithmic_bytes_per_update": algo, "updates_per_launch": n,
                 "kernel": "window_scalar_mul_kernel<%s>" % tag, "kernel_ms": smul_ms / args.steps,
                 "normalize_kernel_ms": norm_ms / args.steps,
@@ -569,7 +668,7 @@ def main():
             run2(dc, 0, dr, 1, tau)
             run2(dc, 0, dr, 1, tau)
             t2 = pkg.phase1_cli.last_timing(dev)
-            p2, _ = pmc_for(KERNEL_TAG[(c2, g2)])
+            p2, _ = pmc_for(KERNEL_TAG[(c2, g2)], args.config)
             m2 = macs_per_update(c2, g2, endo=False)
             entry = {"updates_per_s": n2 / ((t2["scalar_mul_ms"] + t2["normalize_ms"] + t2["subgroup_ms"]) / 1e3), "kernel_ms": t2["scalar_mul_ms"],
                      "normalize_kernel_ms": t2["normalize_ms"], "membership_probe_ms": t2["subgroup_ms"], "points": n2,
@@ -587,6 +686,16 @@ def main():
         if world == 1 and not args.no_extras:
             out["extras"] = whole_chunk_extras(pkg, curve, cfg["power"] if args.log2_points is None else lg,
                                                cfg["log2_chunk"] if args.log2_points is None else lg, dev)
+            # the denominator of "x host-CPU chunk-contribution throughput": the same whole-chunk work on this box's host cores
+            cb = cpu_chunk_baseline(curve, 14 if curve == "bls12_377" else (12 if curve == "bw6" else 10))
+            nidx = 1 << (cfg["log2_chunk"] if args.log2_points is None else lg)
+            cb["projected_chunk_seconds"] = nidx / cb["value"]
+            ex = out["extras"]
+            for k in ("contribute_chunk", "contribute_chunk_exact"):
+                if k in ex:
+                    ex[k]["vs_cpu_all_cores"] = cb["projected_chunk_seconds"] / ex[k]["seconds"]
+                    ex[k]["vs_cpu_all_cores_device_time"] = cb["projected_chunk_seconds"] / (ex[k]["device_ms"] / 1e3)
+            out["cpu_baseline_whole_chunk"] = cb
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
@@ -696,7 +805,7 @@ def bench_verify(args, pkg, dev, rank, world, dist, backend, barrier):
                              "achieved": algo / sub_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo / sub_s / 1e9 / HBM_PEAK_GBS,
                              "traffic": None, "note": "membership tests are ~126 doublings per element: integer-ALU-bound, see DESIGN.md"},
                 "sharded_transform_ratios": sharded,
-                "cpu_baseline": None}))
+                "cpu_baseline": cpu_verify_baseline(lg) if world == 1 else None}))
     finally:
         shutil.rmtree(d, ignore_errors=True)
     if dist is not None:

@@ -234,6 +234,54 @@ struct FpLZ {
         }
         row_finish(acc, out);
     }
+    // (sum_k f_k x_k y_k) / R mod p with ONE reduction: the NP products are accumulated in the same pass of the distributed
+    // row (NP H multiply-accumulates per lane and iteration for the products, H for m p) — a tower product a0 b0 + NR a1 b1
+    // costs 3 H per iteration instead of the 4 H of two reduced products, a three-term one 4 H instead of 6 H, and the sums,
+    // non-residue multiples and carry passes between the partial products disappear.  x_k is scanned (its limb i broadcast to
+    // the pair in iteration i, times the small per-lane factor f_k), y_k is the row operand.  Limb bounds: the units a slot
+    // collects per iteration, sum_k f_k U(x_k) U(y_k) + 1, must stay within 17 (fourteen iterations per lane: < 2^64).
+    template <int NP>
+    PTAU_HD static void row_mul_multi(const uint32_t (&x)[NP][H], const uint32_t (&y)[NP][H], const uint32_t (&f)[NP], uint32_t (&out)[H]) {
+        const bool hi = hi_lane();
+        uint32_t pm[H];
+#pragma unroll
+        for (int j = 0; j < H; j++) pm[j] = hi ? P::MOD[H + j] : P::MOD[j];
+        uint64_t acc[H];
+#pragma unroll
+        for (int j = 0; j < H; j++) acc[j] = 0;
+        // one iteration: the scanned limbs (already broadcast and scaled) against the rows, then m p and the shift of the row
+        auto step = [&](const uint32_t (&xi)[NP]) {
+#pragma unroll
+            for (int k = 0; k < NP; k++) {
+#pragma unroll
+                for (int j = 0; j < H; j++) mac64_vv(acc[j], xi[k], y[k][j]);
+            }
+            const uint32_t m = lane_bcast_even(((uint32_t)acc[0] * P::INV) & MASK);
+#pragma unroll
+            for (int j = 0; j < H; j++) mac64_vv(acc[j], m, pm[j]);
+            const uint64_t x0 = acc[0];
+            const uint32_t recv = lane_xchg((uint32_t)x0 & MASK);
+#pragma unroll
+            for (int j = 0; j + 1 < H; j++) acc[j] = acc[j + 1];
+            acc[0] += x0 >> LB;
+            acc[H - 1] = recv;
+        };
+#pragma unroll
+        for (int i = 0; i < H; i++) {
+            uint32_t xi[NP];
+#pragma unroll
+            for (int k = 0; k < NP; k++) xi[k] = lane_bcast_even(x[k][i]) * f[k];
+            step(xi);
+        }
+#pragma unroll
+        for (int i = 0; i < H; i++) {
+            uint32_t xi[NP];
+#pragma unroll
+            for (int k = 0; k < NP; k++) xi[k] = lane_bcast_odd(x[k][i]) * f[k];
+            step(xi);
+        }
+        row_finish(acc, out);
+    }
     typedef uint32_t VecH __attribute__((ext_vector_type(H)));
     __device__ __noinline__ static VecH mul_vec(VecH a, VecH b) {
         uint32_t x[H], y[H], r[H];

@@ -44,9 +44,15 @@ struct Fp2QZ {
         template <int U2, int V2>
         PTAU_HD operator E<U2, V2>() const { return {c}; }
     };
-    static constexpr int PV = 2 + 2 * NR;        // a product's value bound: t1 + NR t2
+    static constexpr int PV = 2;                 // a product comes out of ONE reduction: below 2p
     static constexpr int SV = 2 + 2 * (Z::subc_k(14, 8));   // a square's: see sqr()
     using Prod = E<1, PV>;
+
+    template <class T>
+    PTAU_HD static auto nrm1(const T &v) {   // limbs below 2^28 (a carry pass only where the bound is looser)
+        if constexpr (T::LIMB_BOUND == 1) return v;
+        else return Z::norm(v);
+    }
 
     PTAU_HD static uint32_t coef() {   // which coefficient this lane's pair holds
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -105,16 +111,45 @@ struct Fp2QZ {
     template <int U, int V>
     PTAU_HD static E<1, V> norm(const E<U, V> &a) { return {Z::norm(a.c)}; }
 
-    // pair 0: a0 b0 + NR a1 b1      pair 1: a1 b0 + a0 b1          (two base products per pair)
+    // pair 0: a0 b0 + NR a1 b1      pair 1: a1 b0 + a0 b1 — ONE fused two-term product per pair (FpLZ::row_mul_multi): the
+    // pair scans its own coefficient of a against b0 and the other pair's (times NR in pair 0) against b1.  Register ABI:
+    // 2 x H VGPRs in, H out; the partner's coefficients arrive by DPP inside.
+    typedef typename Z::VecH VecH;
+    __device__ __noinline__ static VecH mul2_vec(VecH a, VecH b) {
+        uint32_t x[2][H], y[2][H], r[H];
+#pragma unroll
+        for (int i = 0; i < H; i++) {
+            x[0][i] = a[i];
+            x[1][i] = PTAU_DPP(a[i], 0x4E);
+            y[0][i] = PTAU_DPP(b[i], 0x44);
+            y[1][i] = PTAU_DPP(b[i], 0xEE);
+        }
+        const uint32_t f[2] = {1u, coef() ? 1u : (uint32_t)NR};
+        Z::template row_mul_multi<2>(x, y, f, r);
+        VecH o;
+#pragma unroll
+        for (int i = 0; i < H; i++) o[i] = r[i];
+        return o;
+    }
     template <int U1, int V1, int U2, int V2>
     PTAU_HD static Prod mul(const E<U1, V1> &a, const E<U2, V2> &b) {
-        const uint32_t f = coef() ? 1u : (uint32_t)NR;
-        const auto t1 = Z::mul(a.c, from_c0(b.c));          // pair 0: a0 b0   pair 1: a1 b0
-        const auto t2 = Z::mul(other(a.c), from_c1(b.c));   // pair 0: a1 b1   pair 1: a0 b1
-        typename Z::template E<1 + NR, PV> r;
+        static_assert((long long)(1 + NR) * V1 * V2 <= Z::VPROD, "the fused product would not come back below 2p");
+        Prod r;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const auto an = nrm1(a.c);                   // units per iteration: (1 + NR) U1 U2 + 1 <= 17 needs both normalised
+        const auto bn = nrm1(b.c);
+        VecH x, y;
 #pragma unroll
-        for (int i = 0; i < H; i++) r.l[i] = t1.l[i] + t2.l[i] * f;
-        return {Z::norm(r)};
+        for (int i = 0; i < H; i++) { x[i] = an.l[i]; y[i] = bn.l[i]; }
+        const VecH o = mul2_vec(x, y);
+#pragma unroll
+        for (int i = 0; i < H; i++) r.c.l[i] = o[i];
+#else
+        (void)b;
+#pragma unroll
+        for (int i = 0; i < H; i++) r.c.l[i] = a.c.l[i];
+#endif
+        return r;
     }
     // complex squaring, ONE base product per pair:  pair 0: (a0 + a1)(a0 + NR a1) - (1 + NR) a0 a1     pair 1: 2 a0 a1
     template <int U, int V>
@@ -188,9 +223,14 @@ struct Fp3HZ {
         template <int U2, int V2>
         PTAU_HD operator E<U2, V2>() const { return {c}; }
     };
-    static constexpr int PV = 2 + 4 * NR;   // a product: t0 + NR t1 + NR t2
-    static constexpr int SV = 4 + 4 * NR;   // a square:  2 t0 + 2 NR t1
+    static constexpr int PV = 2, SV = 2;    // products and squares come out of ONE reduction: below 2p
     using Prod = E<1, PV>;
+
+    template <class T>
+    PTAU_HD static auto nrm1(const T &v) {   // limbs below 2^28 (a carry pass only where the bound is looser)
+        if constexpr (T::LIMB_BOUND == 1) return v;
+        else return Z::norm(v);
+    }
 
     struct Pos { uint32_t lane, grp, j, base; };   // wave-local lane, group, coefficient, first lane of the group
     PTAU_HD static Pos pos() {
@@ -263,45 +303,116 @@ struct Fp3HZ {
     template <int U, int V>
     PTAU_HD static E<1, V> norm(const E<U, V> &a) { return {Z::norm(a.c)}; }
 
-    // r_j = sum_k a_{j-k} b_k, terms that wrap below u^0 times NR: round k multiplies pair j's a_{(j - k) mod 3} by b_k
-    template <int U1, int V1, int U2, int V2>
-    PTAU_HD static Prod mul(const E<U1, V1> &a, const E<U2, V2> &b) {
-        const uint32_t j = coef();
-        const uint32_t f1 = j < 1u ? (uint32_t)NR : 1u, f2 = j < 2u ? (uint32_t)NR : 1u;
-        const auto t0 = Z::mul(a.c, from_c(b.c, 0));
-        const auto t1 = Z::mul(rot(a.c, 2), from_c(b.c, 1));
-        typename Z::template E<1 + NR, 2 + 2 * NR> s1;
+    // r_j = sum_k a_{(j-k) mod 3} b_k, the terms that wrap below u^0 times NR — ONE fused three-term product per pair
+    // (FpLZ::row_mul_multi): the row operands are b0, b1, b2, the scanned operands this pair's a_j, a_{j-1}, a_{j-2}, taken
+    // from NR a (normalised once, at the source pair) where the term wraps.  Register ABI: 2 x H VGPRs in, H out; every
+    // cross-pair move is a ds_bpermute inside.
+    typedef typename Z::VecH VecH;
+    __device__ __noinline__ static VecH mul3_vec(VecH a, VecH b) {
+        const Pos p = pos();
+        typename Z::template E<1, 1> av;
 #pragma unroll
-        for (int i = 0; i < H; i++) s1.l[i] = t0.l[i] + t1.l[i] * f1;
-        const auto n1 = Z::norm(s1);
-        const auto t2 = Z::mul(rot(a.c, 1), from_c(b.c, 2));
-        typename Z::template E<1 + NR, PV> s2;
-#pragma unroll
-        for (int i = 0; i < H; i++) s2.l[i] = n1.l[i] + t2.l[i] * f2;
-        return {Z::norm(s2)};
-    }
-    // r0 = a0^2 + 2 NR a1 a2,  r1 = 2 a0 a1 + NR a2^2,  r2 = 2 a0 a2 + a1^2: two base products per pair
-    template <int U, int V>
-    PTAU_HD static E<1, SV> sqr(const E<U, V> &a) {
-        const uint32_t j = coef();
-        const auto r1 = rot(a.c, 1), r2 = rot(a.c, 2);
-        const auto t0 = Z::mul(from_c(a.c, 0), a.c);          // a0^2 | a0 a1 | a0 a2
-        typename Z::template E<U, V> x, y;
+        for (int i = 0; i < H; i++) av.l[i] = a[i];
+        const auto an = Z::norm(Z::template times<NR>(av));   // NR a, limbs below 2^28 again
+        const uint32_t h = p.lane & 1u;
+        const uint32_t jm1 = p.j == 0u ? 2u : p.j - 1u, jm2 = p.j == 2u ? 0u : p.j + 1u;   // (j - 1) mod 3, (j - 2) mod 3
+        const uint32_t s1 = p.base + 2u * jm1 + h, s2 = p.base + 2u * jm2 + h;
+        uint32_t x[3][H], y[3][H], r[H];
 #pragma unroll
         for (int i = 0; i < H; i++) {
-            x.l[i] = j == 2u ? r2.l[i] : r1.l[i];               // a1 | a2 | a1
-            y.l[i] = j == 1u ? r1.l[i] : r2.l[i];               // a2 | a2 | a1
+            // what this pair SENDS: to pair j + 1 (which wraps iff j == 2) and to pair j + 2 (wraps iff j >= 1)
+            const uint32_t to1 = p.j == 2u ? an.l[i] : a[i], to2 = p.j >= 1u ? an.l[i] : a[i];
+            x[0][i] = a[i];
+            x[1][i] = bperm(s1, to1);
+            x[2][i] = bperm(s2, to2);
+            y[0][i] = bperm(p.base + h, b[i]);
+            y[1][i] = bperm(p.base + 2u + h, b[i]);
+            y[2][i] = bperm(p.base + 4u + h, b[i]);
         }
-        const auto t1 = Z::mul(x, y);                          // a1 a2 | a2^2 | a1^2
-        const uint32_t f0 = j == 0u ? 1u : 2u, g1 = j == 2u ? 1u : (uint32_t)NR, g2 = j == 0u ? (uint32_t)NR : 0u;
-        typename Z::template E<2 + NR, 4 + 2 * NR> s1;
+        const uint32_t f[3] = {1u, 1u, 1u};
+        Z::template row_mul_multi<3>(x, y, f, r);
+        VecH o;
 #pragma unroll
-        for (int i = 0; i < H; i++) s1.l[i] = t0.l[i] * f0 + t1.l[i] * g1;
-        const auto n1 = Z::norm(s1);
-        typename Z::template E<1 + NR, SV> s2;
+        for (int i = 0; i < H; i++) o[i] = r[i];
+        return o;
+    }
+    // r0 = a0 a0 + (2 NR a1) a2,  r1 = (2 a0) a1 + (NR a2) a2,  r2 = (2 a0) a2 + a1 a1: one fused two-term product per pair
+    __device__ __noinline__ static VecH sqr3_vec(VecH a) {
+        const Pos p = pos();
+        typename Z::template E<1, 1> av;
 #pragma unroll
-        for (int i = 0; i < H; i++) s2.l[i] = n1.l[i] + t1.l[i] * g2;
-        return {Z::norm(s2)};
+        for (int i = 0; i < H; i++) av.l[i] = a[i];
+        const auto an = Z::norm(Z::template times<NR>(av));
+        const uint32_t h = p.lane & 1u;
+        const uint32_t j1 = p.j == 2u ? 0u : p.j + 1u, j2 = p.j == 0u ? 2u : p.j - 1u;      // (j + 1) mod 3, (j + 2) mod 3
+        const uint32_t s1 = p.base + 2u * j1 + h, s2 = p.base + 2u * j2 + h;
+        uint32_t x[2][H], y[2][H], r[H];
+#pragma unroll
+        for (int i = 0; i < H; i++) {
+            const uint32_t a0 = bperm(p.base + h, a[i]);
+            // second term: pair 0 wants (NR a1, a2), pair 1 (NR a2, a2), pair 2 (a1, a1)
+            const uint32_t r1n = bperm(s1, an.l[i]);                 // NR a_{j+1}:  NR a1 | NR a2 | NR a0
+            const uint32_t r1p = bperm(s1, a[i]);                    //    a_{j+1}:     a1 |    a2 |    a0
+            const uint32_t r2 = bperm(s2, a[i]);                     //    a_{j+2}:     a2 |    a0 |    a1
+            x[0][i] = a0;
+            y[0][i] = a[i];
+            x[1][i] = p.j == 2u ? r2 : r1n;                          // NR a1 | NR a2 | a1
+            y[1][i] = p.j == 1u ? r1p : r2;                          // a2    | a2    | a1
+        }
+        const uint32_t f[2] = {p.j == 0u ? 1u : 2u, p.j == 0u ? 2u : 1u};
+        Z::template row_mul_multi<2>(x, y, f, r);
+        VecH o;
+#pragma unroll
+        for (int i = 0; i < H; i++) o[i] = r[i];
+        return o;
+    }
+    template <int U1, int V1, int U2, int V2>
+    PTAU_HD static Prod mul(const E<U1, V1> &a, const E<U2, V2> &b) {
+        static_assert((long long)(1 + 2 * NR) * V1 * V2 <= Z::VPROD, "the fused product would not come back below 2p");
+        Prod r;
+#if defined(__HIP_DEVICE_COMPILE__)
+        // the scanned operand must be normalised (its NR multiple is formed inside); the row operand may carry limbs up to
+        // 5 x 2^28 (3 U + 1 <= 17 units per iteration).  The product commutes: scan the normalised one.
+        VecH x, y;
+        if constexpr (U1 == 1 && U2 <= 5) {
+#pragma unroll
+            for (int i = 0; i < H; i++) { x[i] = a.c.l[i]; y[i] = b.c.l[i]; }
+        } else if constexpr (U2 == 1 && U1 <= 5) {
+#pragma unroll
+            for (int i = 0; i < H; i++) { x[i] = b.c.l[i]; y[i] = a.c.l[i]; }
+        } else {
+            const auto an = nrm1(a.c);
+            const auto bn = Z::norm(b.c);
+#pragma unroll
+            for (int i = 0; i < H; i++) { x[i] = an.l[i]; y[i] = bn.l[i]; }
+        }
+        const VecH o = mul3_vec(x, y);
+#pragma unroll
+        for (int i = 0; i < H; i++) r.c.l[i] = o[i];
+#else
+        (void)b;
+#pragma unroll
+        for (int i = 0; i < H; i++) r.c.l[i] = a.c.l[i];
+#endif
+        return r;
+    }
+    template <int U, int V>
+    PTAU_HD static Prod sqr(const E<U, V> &a) {
+        static_assert((long long)(2 + 2 * NR) * V * V <= Z::VPROD, "the fused square would not come back below 2p");
+        Prod r;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const auto an = nrm1(a.c);
+        VecH x;
+#pragma unroll
+        for (int i = 0; i < H; i++) x[i] = an.l[i];
+        const VecH o = sqr3_vec(x);
+#pragma unroll
+        for (int i = 0; i < H; i++) r.c.l[i] = o[i];
+#else
+#pragma unroll
+        for (int i = 0; i < H; i++) r.c.l[i] = a.c.l[i];
+#endif
+        return r;
     }
     // a * v for the twist coefficient a = A u^2:  (c0, c1, c2) u^2 = (NR c1, NR c2, c0)
     template <int A, int V>

@@ -50,6 +50,7 @@ def main():
             d[c + "_launches"] = n
         if "FETCH_SIZE_per_launch" in d and "WRITE_SIZE_per_launch" in d:
             d["hbm_bytes_per_launch"] = (2.0 * d["FETCH_SIZE_per_launch"] + d["WRITE_SIZE_per_launch"]) * 1024.0
+            d["hbm_bytes_per_launch_raw_fetch"] = (d["FETCH_SIZE_per_launch"] + d["WRITE_SIZE_per_launch"]) * 1024.0
         if "SQ_WAIT_ANY_per_launch" in d and d.get("SQ_WAVE_CYCLES_per_launch"):
             d["wait_any_frac_of_wave_cycles"] = d["SQ_WAIT_ANY_per_launch"] / d["SQ_WAVE_CYCLES_per_launch"]
         kernels[k] = d
