@@ -240,8 +240,11 @@ struct FpLZ {
     // non-residue multiples and carry passes between the partial products disappear.  x_k is scanned (its limb i broadcast to
     // the pair in iteration i, times the small per-lane factor f_k), y_k is the row operand.  Limb bounds: the units a slot
     // collects per iteration, sum_k f_k U(x_k) U(y_k) + 1, must stay within 17 (fourteen iterations per lane: < 2^64).
-    template <int NP>
-    PTAU_HD static void row_mul_multi(const uint32_t (&x)[NP][H], const uint32_t (&y)[NP][H], const uint32_t (&f)[NP], uint32_t (&out)[H]) {
+    // General form: scan(k, i) delivers limb i (0 <= i < N) of the k-th scanned operand, already broadcast to the pair and
+    // scaled — the caller decides where it comes from (a DPP broadcast of a register, a ds_bpermute from another pair's lane
+    // issued just in time, so that the scanned operands need not be held in registers).
+    template <int NP, class Scan>
+    PTAU_HD static void row_mul_scan(const Scan &scan, const uint32_t (&y)[NP][H], uint32_t (&out)[H]) {
         const bool hi = hi_lane();
         uint32_t pm[H];
 #pragma unroll
@@ -249,7 +252,7 @@ struct FpLZ {
         uint64_t acc[H];
 #pragma unroll
         for (int j = 0; j < H; j++) acc[j] = 0;
-        // one iteration: the scanned limbs (already broadcast and scaled) against the rows, then m p and the shift of the row
+        // one iteration: the scanned limbs against the rows, then m p and the shift of the row
         auto step = [&](const uint32_t (&xi)[NP]) {
 #pragma unroll
             for (int k = 0; k < NP; k++) {
@@ -266,21 +269,27 @@ struct FpLZ {
             acc[0] += x0 >> LB;
             acc[H - 1] = recv;
         };
+        // (two loops of H: one loop of N iterations exceeds the full-unroll budget and is left rolled, its operands in scratch)
 #pragma unroll
         for (int i = 0; i < H; i++) {
             uint32_t xi[NP];
 #pragma unroll
-            for (int k = 0; k < NP; k++) xi[k] = lane_bcast_even(x[k][i]) * f[k];
+            for (int k = 0; k < NP; k++) xi[k] = scan(k, i);
             step(xi);
         }
 #pragma unroll
-        for (int i = 0; i < H; i++) {
+        for (int i = H; i < N; i++) {
             uint32_t xi[NP];
 #pragma unroll
-            for (int k = 0; k < NP; k++) xi[k] = lane_bcast_odd(x[k][i]) * f[k];
+            for (int k = 0; k < NP; k++) xi[k] = scan(k, i);
             step(xi);
         }
         row_finish(acc, out);
+    }
+    template <int NP>
+    PTAU_HD static void row_mul_multi(const uint32_t (&x)[NP][H], const uint32_t (&y)[NP][H], const uint32_t (&f)[NP], uint32_t (&out)[H]) {
+        row_mul_scan<NP>([&](int k, int i) { return (i < H ? lane_bcast_even(x[k][i < H ? i : 0]) : lane_bcast_odd(x[k][i < H ? 0 : i - H])) * f[k]; },
+                         y, out);
     }
     typedef uint32_t VecH __attribute__((ext_vector_type(H)));
     __device__ __noinline__ static VecH mul_vec(VecH a, VecH b) {

@@ -194,6 +194,39 @@ struct FpZ {
             acc >>= LB;
         }
     }
+    // (a b + c d) / R mod p with ONE reduction (product scanning, both products in every column): 2 N^2 + N (N - 1) multiply-
+    // accumulates instead of the 2 (N^2 + N (N - 1)) of two reduced products.  Column sums: N products a_j b_k (< U1 U2 2^56),
+    // N products c_j d_k (< U3 U4 2^56) and N products m_j p_k: U1 U2 + U3 U4 <= 16 keeps them below 2^64.
+    PTAU_HD static void ps_mul2(const uint32_t (&a)[N], const uint32_t (&b)[N], const uint32_t (&c)[N], const uint32_t (&d)[N],
+                                uint32_t (&out)[N]) {
+        uint32_t m[N];
+        uint64_t acc = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+#pragma unroll
+            for (int j = 0; j <= i; j++) {
+                mac64_vv(acc, a[j], b[i - j]);
+                mac64_vv(acc, c[j], d[i - j]);
+            }
+#pragma unroll
+            for (int j = 0; j < i; j++) mac64_vs(acc, m[j], P::MOD[i - j]);
+            m[i] = (0u - (uint32_t)acc) & MASK;   // INV = -1
+            acc += m[i];                           // MOD[0] = 1
+            acc >>= LB;
+        }
+#pragma unroll
+        for (int i = N; i < 2 * N; i++) {
+#pragma unroll
+            for (int j = i - N + 1; j < N; j++) {
+                mac64_vv(acc, a[j], b[i - j]);
+                mac64_vv(acc, c[j], d[i - j]);
+            }
+#pragma unroll
+            for (int j = i - N + 1; j < N; j++) mac64_vs(acc, m[j], P::MOD[i - j]);
+            out[i - N] = i == 2 * N - 1 ? (uint32_t)acc : ((uint32_t)acc & MASK);
+            acc >>= LB;
+        }
+    }
     typedef uint32_t VecN __attribute__((ext_vector_type(N)));
     __host__ __device__ __noinline__ static VecN mul_vec(VecN a, VecN b) {
         uint32_t x[N], y[N], r[N];
@@ -405,7 +438,7 @@ struct Fp2Z {
         template <int U2, int V2>
         PTAU_HD operator E<U2, V2>() const { return {c}; }
     };
-    using M = E<1, 13>;   // a product
+    using M = E<1, 2>;    // a product (one fused two-term product per lane, one reduction: below 2p)
     using S = E<1, 10>;   // a square
     using R = E<1, 3>;    // after reduce()
     using Nrm = typename Z::Nrm;
@@ -447,19 +480,61 @@ struct Fp2Z {
     template <int U, int V, class KT>
     PTAU_HD static E<1, 2> mul_base(const E<U, V> &a, const KT &k) { return {Z::mul(a.c, k)}; }
 
+    // even lane: a0 b0 - 5 a1 b1 = a0 b0 + (5 (KN p - a1)) b1      odd lane: a1 b0 + a0 b1 — ONE fused two-term product per lane
+    // (FpZ::ps_mul2, one reduction).  The negation uses a FIXED multiple KN p (one out-of-line copy serves every call site):
+    // the operand passed as `a` must be normalised with a value below (KN - 1) p.  Register ABI: 2 x N VGPRs in, N out; the
+    // partner's coefficients arrive by DPP inside.
+    static constexpr int KN = 32;
+    typedef typename Z::VecN VecN;
+    __device__ __noinline__ static VecN mul2_vec(VecN a, VecN b) {
+        const bool odd = lane_parity() != 0;
+        uint32_t x1[N], y1[N], x2[N], y2[N], r[N];
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const uint32_t ao = lane_xchg(a[i]);
+            const uint32_t ng = Z::template SubC<KN, 2>::v.l[i] - ao;        // limb of KN p - a1 (biased: no borrow)
+            x1[i] = a[i];
+            y1[i] = lane_bcast_even(b[i]);
+            x2[i] = odd ? ao : (ng << 2) + ng;                                 // odd: a0     even: 5 (KN p - a1)
+            y2[i] = lane_bcast_odd(b[i]);
+        }
+        Z::ps_mul2(x1, y1, x2, y2, r);
+        VecN o;
+#pragma unroll
+        for (int i = 0; i < N; i++) o[i] = r[i];
+        return o;
+    }
+    template <class T>
+    PTAU_HD static auto nrm1(const T &v) {
+        if constexpr (T::LIMB_BOUND == 1) return v;
+        else return Z::norm(v);
+    }
     template <int U1, int V1, int U2, int V2>
     PTAU_HD static M mul(const E<U1, V1> &a, const E<U2, V2> &b) {
-        const bool odd = lane_parity() != 0;
-        typename Z::template E<U2, V2> b0, b1;
+        // scan-side choice: the operand whose value bound fits the fixed negation constant goes first (the product commutes)
+        if constexpr (V1 > KN - 1 && V2 <= KN - 1) {
+            return mul(b, a);
+        } else {
+            static_assert(V1 <= KN - 1, "fused Fq2 product: one operand must stay below (KN - 1) p");
+            // column units: 1 (a0 b0) + 15 (5 x the biased negation, limbs below 3 x 2^28) = 16: both operands normalised
+            static_assert((long long)(V1 + 5 * (KN + 1)) * V2 <= (1 << 15), "the fused product would not come back below 2p");
+            M r;
+#if defined(__HIP_DEVICE_COMPILE__)
+            const auto an = nrm1(a.c);
+            const auto bn = nrm1(b.c);
+            VecN x, y;
 #pragma unroll
-        for (int i = 0; i < N; i++) { b0.l[i] = lane_bcast_even(b.c.l[i]); b1.l[i] = lane_bcast_odd(b.c.l[i]); }
-        const Nrm t1 = Z::mul(a.c, b0);                        // even a0 b0   odd a1 b0
-        const Nrm t2 = Z::mul(other(a.c), b1);                 // even a1 b1   odd a0 b1
-        const auto m5 = Z::sub(t1, Z::template times<5>(t2));  // <8, 13>
-        typename Z::template E<8, 13> r;
+            for (int i = 0; i < N; i++) { x[i] = an.l[i]; y[i] = bn.l[i]; }
+            const VecN o = mul2_vec(x, y);
 #pragma unroll
-        for (int i = 0; i < N; i++) r.l[i] = odd ? t1.l[i] + t2.l[i] : m5.l[i];
-        return {Z::norm(r)};
+            for (int i = 0; i < N; i++) r.c.l[i] = o[i];
+#else
+            (void)b;
+#pragma unroll
+            for (int i = 0; i < N; i++) r.c.l[i] = a.c.l[i];
+#endif
+            return r;
+        }
     }
     template <int V>
     PTAU_HD static S sqr(const E<1, V> &a) {

@@ -138,12 +138,39 @@ __device__ inline int window_scalar_mul_lazy_a_thread(const uint8_t *__restrict_
             w[2 * H + t] = qinf ? 0u : K::raw(q.Zc).l[t];
         }
     };
+    // the second operand of an addition, read where the formula uses it (LazyJacA::add)
+    struct FromRegs {   // P itself while the table is built
+        const CT &x_, &y_, &z_;
+        PTAU_HD CT x() const { return x_; }
+        PTAU_HD CT y() const { return y_; }
+        PTAU_HD CT z() const { return z_; }
+    };
+    struct FromTable {  // a table entry, its y negated on the way in when the digit is negative
+        const uint32_t *e;
+        bool negate;
+        PTAU_HD CT load(int c) const {
+            CT v;
+            const volatile uint32_t *w = e + c * H;   // volatile: the loads stay where the formula consumes the value
+#pragma unroll
+            for (int t = 0; t < H; t++) K::raw(v).l[t] = w[t];
+            return v;
+        }
+        PTAU_HD CT x() const { return load(0); }
+        PTAU_HD auto y() const {
+            const CT v = load(1);
+            const auto nv = K::neg(v);
+            decltype(K::neg(v)) r = v;
+            if (negate) r = nv;
+            return r;
+        }
+        PTAU_HD CT z() const { return load(2); }
+    };
     {
         Acc cur = {px, py, pz};
         store_entry(0, cur);
 #pragma nounroll
         for (int e = 1; e < WINDOW_ENTRIES; e++) {
-            cur = Acc::add(cur, px, py, pz);
+            cur = Acc::add(cur, FromRegs{px, py, pz});
             store_entry(e, cur);
         }
     }
@@ -165,20 +192,8 @@ __device__ inline int window_scalar_mul_lazy_a_thread(const uint8_t *__restrict_
         const int dgt = (int)((limb >> ((w & 7) * 4)) & 15u) - 8;
         if (dgt != 0) {
             const int mag = dgt < 0 ? -dgt : dgt;
-            const uint32_t *e = entry(mag - 1);
-            CT ex, ey, ez;
-#pragma unroll
-            for (int t = 0; t < H; t++) {
-                K::raw(ex).l[t] = e[t];
-                K::raw(ey).l[t] = e[H + t];
-                K::raw(ez).l[t] = e[2 * H + t];
-            }
-            if (!K::limbs_all_zero(ez)) {   // the multiple is not O
-                const auto ny = K::neg(ey);
-                decltype(K::neg(ey)) ys = ey;
-                if (dgt < 0) ys = ny;
-                acc = Acc::add(acc, ex, ys, ez);
-            }
+            const FromTable ent{entry(mag - 1), dgt < 0};
+            if (!K::limbs_all_zero(ent.z())) acc = Acc::add(acc, ent);   // the multiple is not O
         }
     }
     // ---- back to the reduced field, standard layout ----

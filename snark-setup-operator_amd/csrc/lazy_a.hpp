@@ -151,11 +151,17 @@ struct Fp2QZ {
 #endif
         return r;
     }
-    // complex squaring, ONE base product per pair:  pair 0: (a0 + a1)(a0 + NR a1) - (1 + NR) a0 a1     pair 1: 2 a0 a1
-    template <int U, int V>
-    PTAU_HD static E<1, SV> sqr(const E<U, V> &a_in) {
+    // complex squaring, ONE base product per pair:  pair 0: (a0 + a1)(a0 + NR a1) - (1 + NR) a0 a1     pair 1: 2 a0 a1.
+    // Out of line with a register ABI (H VGPRs in, H out): the sums, the product and the correction live in the callee, the
+    // window loop's code stays small (eight squares per doubling) and the glue's temporaries are not alive across calls.
+    // The operand: normalised, below SQ_VIN p.
+    static constexpr int SQ_VIN = 6144;
+    __device__ __noinline__ static VecH sqr2_vec(VecH av) {
         static_assert((1 + NR) % 2 == 0 && (1 + NR) / 2 <= 7, "the correction (1 + NR) a0 a1 is subtracted in two halves");
-        const auto a = Z::norm(a_in.c);
+        constexpr int V = SQ_VIN;
+        typename Z::template E<1, V> a;
+#pragma unroll
+        for (int i = 0; i < H; i++) a.l[i] = av[i];
         const uint32_t m0 = coef() ? 0u : 0xffffffffu;      // all ones in the pair that holds c0
         const auto ot = other(a);
         const auto nr = Z::template times<NR>(ot);
@@ -166,17 +172,47 @@ struct Fp2QZ {
             l.l[i] = ot.l[i] + (a.l[i] & m0);                // pair 0: a0 + a1        pair 1: a0
             r.l[i] = a.l[i] + (nr.l[i] & m0);                // pair 0: a0 + NR a1     pair 1: a1
         }
-        const auto t = Z::mul(l, Z::norm(r));                // pair 0: (a0 + a1)(a0 + NR a1)     pair 1: a0 a1
+        const auto rn = Z::norm(r);
+        uint32_t lx[H], rx[H], tx[H];
+#pragma unroll
+        for (int i = 0; i < H; i++) { lx[i] = l.l[i]; rx[i] = rn.l[i]; }
+        static_assert((long long)2 * V * (1 + NR) * V <= Z::VPROD, "the square's product would not come back below 2p");
+        Z::row_mul(lx, rx, tx);                               // pair 0: (a0 + a1)(a0 + NR a1)     pair 1: a0 a1
+        typename Z::Nrm t;
+#pragma unroll
+        for (int i = 0; i < H; i++) t.l[i] = tx[i];
         const auto v = from_c1(t);
         constexpr int HK = (1 + NR) / 2;
         const auto hv = Z::template times<HK>(v);
         const auto d1 = Z::norm(Z::sub(t, hv));
         const auto d2 = Z::sub(d1, hv);                       // t - (1 + NR) a0 a1 + a multiple of p
+        static_assert(decltype(d2)::VALUE_BOUND <= SV, "square bound");
         typename Z::template E<decltype(d2)::LIMB_BOUND, decltype(d2)::VALUE_BOUND> o;
 #pragma unroll
         for (int i = 0; i < H; i++) o.l[i] = m0 ? d2.l[i] : t.l[i] + t.l[i];
-        static_assert(decltype(d2)::VALUE_BOUND <= SV, "square bound");
-        return {Z::norm(o)};
+        const auto on = Z::norm(o);
+        VecH out;
+#pragma unroll
+        for (int i = 0; i < H; i++) out[i] = on.l[i];
+        return out;
+    }
+    template <int U, int V>
+    PTAU_HD static E<1, SV> sqr(const E<U, V> &a_in) {
+        static_assert(V <= SQ_VIN, "operand of the out-of-line Fq2 square out of range");
+        E<1, SV> r;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const auto a = nrm1(a_in.c);
+        VecH x;
+#pragma unroll
+        for (int i = 0; i < H; i++) x[i] = a.l[i];
+        const VecH o = sqr2_vec(x);
+#pragma unroll
+        for (int i = 0; i < H; i++) r.c.l[i] = o[i];
+#else
+#pragma unroll
+        for (int i = 0; i < H; i++) r.c.l[i] = a_in.c.l[i];
+#endif
+        return r;
     }
     // a * v for the twist coefficient a = A_SMALL in the base field
     template <int A, int V>
@@ -316,21 +352,23 @@ struct Fp3HZ {
         const auto an = Z::norm(Z::template times<NR>(av));   // NR a, limbs below 2^28 again
         const uint32_t h = p.lane & 1u;
         const uint32_t jm1 = p.j == 0u ? 2u : p.j - 1u, jm2 = p.j == 2u ? 0u : p.j + 1u;   // (j - 1) mod 3, (j - 2) mod 3
-        const uint32_t s1 = p.base + 2u * jm1 + h, s2 = p.base + 2u * jm2 + h;
-        uint32_t x[3][H], y[3][H], r[H];
+        uint32_t y[3][H], r[H];
 #pragma unroll
         for (int i = 0; i < H; i++) {
-            // what this pair SENDS: to pair j + 1 (which wraps iff j == 2) and to pair j + 2 (wraps iff j >= 1)
-            const uint32_t to1 = p.j == 2u ? an.l[i] : a[i], to2 = p.j >= 1u ? an.l[i] : a[i];
-            x[0][i] = a[i];
-            x[1][i] = bperm(s1, to1);
-            x[2][i] = bperm(s2, to2);
             y[0][i] = bperm(p.base + h, b[i]);
             y[1][i] = bperm(p.base + 2u + h, b[i]);
             y[2][i] = bperm(p.base + 4u + h, b[i]);
         }
-        const uint32_t f[3] = {1u, 1u, 1u};
-        Z::template row_mul_multi<3>(x, y, f, r);
+        // The scanned limbs are fetched where they are consumed (limb i of a_{j-k} sits in register i mod H of the low / high
+        // lane of pair j - k; what that pair SENDS is NR a where the term wraps: to pair j + 1 iff it is pair 2, to pair
+        // j + 2 iff it is pair 1 or 2), so only a and NR a are held: the callee stays within the caller-saved registers.
+        Z::template row_mul_scan<3>([&](int k, int i) {
+            const int t = i < H ? i : i - H;
+            const uint32_t top = i < H ? 0u : 1u;
+            if (k == 0) return i < H ? lane_bcast_even(a[t]) : lane_bcast_odd(a[t]);
+            if (k == 1) return bperm(p.base + 2u * jm1 + top, p.j == 2u ? an.l[t] : a[t]);
+            return bperm(p.base + 2u * jm2 + top, p.j >= 1u ? an.l[t] : a[t]);
+        }, y, r);
         VecH o;
 #pragma unroll
         for (int i = 0; i < H; i++) o[i] = r[i];
@@ -345,22 +383,25 @@ struct Fp3HZ {
         const auto an = Z::norm(Z::template times<NR>(av));
         const uint32_t h = p.lane & 1u;
         const uint32_t j1 = p.j == 2u ? 0u : p.j + 1u, j2 = p.j == 0u ? 2u : p.j - 1u;      // (j + 1) mod 3, (j + 2) mod 3
-        const uint32_t s1 = p.base + 2u * j1 + h, s2 = p.base + 2u * j2 + h;
-        uint32_t x[2][H], y[2][H], r[H];
+        uint32_t y[2][H], r[H];
 #pragma unroll
         for (int i = 0; i < H; i++) {
-            const uint32_t a0 = bperm(p.base + h, a[i]);
-            // second term: pair 0 wants (NR a1, a2), pair 1 (NR a2, a2), pair 2 (a1, a1)
-            const uint32_t r1n = bperm(s1, an.l[i]);                 // NR a_{j+1}:  NR a1 | NR a2 | NR a0
-            const uint32_t r1p = bperm(s1, a[i]);                    //    a_{j+1}:     a1 |    a2 |    a0
-            const uint32_t r2 = bperm(s2, a[i]);                     //    a_{j+2}:     a2 |    a0 |    a1
-            x[0][i] = a0;
+            // rows: a_j | then a2, a2, a1
+            const uint32_t r1p = bperm(p.base + 2u * j1 + h, a[i]);   // a_{j+1}: a1 | a2 | a0
+            const uint32_t r2 = bperm(p.base + 2u * j2 + h, a[i]);    // a_{j+2}: a2 | a0 | a1
             y[0][i] = a[i];
-            x[1][i] = p.j == 2u ? r2 : r1n;                          // NR a1 | NR a2 | a1
-            y[1][i] = p.j == 1u ? r1p : r2;                          // a2    | a2    | a1
+            y[1][i] = p.j == 1u ? r1p : r2;
         }
-        const uint32_t f[2] = {p.j == 0u ? 1u : 2u, p.j == 0u ? 2u : 1u};
-        Z::template row_mul_multi<2>(x, y, f, r);
+        const uint32_t f0 = p.j == 0u ? 1u : 2u, f1 = p.j == 0u ? 2u : 1u;
+        // scanned: a0 (times 2 off pair 0) | then NR a1, NR a2, a1 (times 2 in pair 0)
+        Z::template row_mul_scan<2>([&](int k, int i) {
+            const int t = i < H ? i : i - H;
+            const uint32_t top = i < H ? 0u : 1u;
+            if (k == 0) return bperm(p.base + top, a[t]) * f0;
+            const uint32_t r1n = bperm(p.base + 2u * j1 + top, an.l[t]);   // NR a_{j+1}
+            const uint32_t r2s = bperm(p.base + 2u * j2 + top, a[t]);      //    a_{j+2}
+            return (p.j == 2u ? r2s : r1n) * f1;
+        }, y, r);
         VecH o;
 #pragma unroll
         for (int i = 0; i < H; i++) o[i] = r[i];
@@ -484,46 +525,59 @@ struct LazyJacA {
         else return K::template mul_by_a<Cfg::A_SMALL>(zz2);
     }
 
-    // dbl-2007-bl: 1M + 8S.  The point at infinity maps to itself (Z3 = 2 Y1 Z1).
+    // dbl-2007-bl: 1M + 8S.  The point at infinity maps to itself (Z3 = 2 Y1 Z1).  Ordered so that at most six field
+    // elements are alive at any product call: the register-ABI callee leaves the caller 112 VGPRs (the callee-saved half of
+    // v32-v255), and every value alive across a call beyond that is a scratch store and reload — the whole HBM traffic of
+    // this kernel (profiles/r03_pmc_cfg4*.json).
     PTAU_HD static LazyJacA dbl(const LazyJacA &p) {
-        const auto XX = K::sqr(p.X);
         const auto YY = K::sqr(p.Y);
-        const auto YYYY = K::sqr(YY);
         const auto ZZ = K::sqr(p.Zc);
-        const auto t = K::sqr(K::norm(K::add(p.X, YY)));
-        const auto S = K::norm(K::template times<2>(K::sub(t, K::add(XX, YYYY))));
-        const auto M = K::norm(K::add(K::template times<3>(XX), a_times(K::norm(K::sqr(ZZ)))));
         LazyJacA r;
+        r.Zc = K::norm(K::sub(K::sqr(K::add(p.Y, p.Zc)), K::add(YY, ZZ)));
+        const auto ZZ2 = K::sqr(ZZ);
+        const auto XX = K::sqr(p.X);
+        const auto M = K::norm(K::add(K::template times<3>(XX), a_times(ZZ2)));
+        const auto YYYY = K::sqr(YY);
+        const auto t = K::sqr(K::add(p.X, YY));
+        const auto S = K::norm(K::template times<2>(K::sub(t, K::add(XX, YYYY))));
         r.X = K::norm(K::sub(K::sqr(M), K::template times<2>(S)));
-        r.Y = K::norm(K::sub(K::mul(M, K::norm(K::sub(S, r.X))), K::template times<8>(YYYY)));
-        r.Zc = K::norm(K::sub(K::sqr(K::norm(K::add(p.Y, p.Zc))), K::add(YY, ZZ)));
+        r.Y = K::norm(K::sub(K::mul(M, K::sub(S, r.X)), K::template times<8>(YYYY)));
         return r;
     }
 
-    // add-2007-bl: 11M + 5S; (x2, y2, z2) = a table entry (y2 possibly negated on the fly), never the point at infinity
-    template <class XT, class YT, class ZT>
-    PTAU_HD static LazyJacA add(const LazyJacA &p, const XT &x2, const YT &y2, const ZT &z2) {
-        const auto Z1Z1 = K::sqr(p.Zc);
-        const auto Z2Z2 = K::sqr(z2);
+    // add-2007-bl with Z3 = 2 Z1 Z2 H: 12M + 4S.  The second operand is a TABLE ENTRY that is read from memory where it is
+    // used (src.x(), src.y(), src.z(): one use each but z, which is read first and consumed by three products), never held
+    // across calls; the exceptional cases (p = O, p = +-q) are rebuilt from the entry as well, so p's coordinates die as soon
+    // as the formula has consumed them: at most seven field elements are alive at any product call.
+    // src.y() returns the entry's y already negated when the digit is negative; the entry is never the point at infinity.
+    template <class Src>
+    PTAU_HD static LazyJacA add(const LazyJacA &p, const Src &src) {
+        const bool pinf = p.is_inf();
+        const auto Z12 = [&] {
+            const auto z2 = src.z();
+            return K::mul(p.Zc, z2);
+        }();
+        const auto Z2Z2 = K::sqr(src.z());
         const auto U1 = K::mul(p.X, Z2Z2);
-        const auto U2 = K::mul(x2, Z1Z1);
-        const auto S1 = K::mul(K::mul(p.Y, z2), Z2Z2);
-        const auto S2 = K::mul(K::mul(K::norm(y2), p.Zc), Z1Z1);
+        const auto S1 = K::mul(K::mul(p.Y, src.z()), Z2Z2);
+        const auto Z1Z1 = K::sqr(p.Zc);
+        const auto U2 = K::mul(src.x(), Z1Z1);
+        const auto S2 = K::mul(K::mul(src.y(), p.Zc), Z1Z1);
         const auto Hh = K::norm(K::sub(U2, U1));
         const auto rh = K::norm(K::sub(S2, S1));
         const auto I = K::sqr(K::template times<2>(Hh));
         const auto J = K::mul(Hh, I);
         const auto Vv = K::mul(U1, I);
-        const auto rr = K::template times<2>(rh);
         LazyJacA r;
+        r.Zc = K::norm(K::template times<2>(K::mul(Z12, Hh)));
+        const auto rr = K::template times<2>(rh);
         r.X = K::norm(K::sub(K::sqr(rr), K::add(J, K::template times<2>(Vv))));
-        r.Y = K::norm(K::sub(K::mul(rr, K::norm(K::sub(Vv, r.X))), K::template times<2>(K::mul(S1, J))));
-        r.Zc = K::mul(K::norm(K::sub(K::sqr(K::norm(K::add(p.Zc, z2))), K::add(Z1Z1, Z2Z2))), Hh);
-        // exceptional cases overwrite the generic result: one join, rare paths
-        const bool pinf = p.is_inf();
+        r.Y = K::norm(K::sub(K::mul(rr, K::sub(Vv, r.X)), K::template times<2>(K::mul(S1, J))));
+        // exceptional cases overwrite the generic result: one join, rare paths, everything rebuilt from the entry
         if (pinf || K::is_zero(Hh)) {
-            if (pinf) r = {x2, K::mul(K::norm(y2), K::one()), z2};   // y2 may carry a negation's bound: back below a product's
-            else if (K::is_zero(rh)) r = dbl(p);
+            const LazyJacA q = {src.x(), K::mul(K::norm(src.y()), K::one()), src.z()};   // y may carry a negation's bound
+            if (pinf) r = q;
+            else if (K::is_zero(rh)) r = dbl(q);
             else r = infinity();
         }
         return r;
