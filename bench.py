@@ -575,6 +575,7 @@ def main():
     for _ in range(args.warmup):
         run(d_chal, 0, d_resp, 1, tau)
     barrier()
+    busy0 = L.ptau_device_busy_ms(dev)
     t0 = time.perf_counter()
     smul_ms = norm_ms = 0.0
     for _ in range(args.steps):
@@ -584,6 +585,12 @@ def main():
         norm_ms += tm["normalize_ms"]
     barrier()
     dt = time.perf_counter() - t0
+    # kernel time of THIS rank's device over the timed region (ptau_device_busy_ms): one entry per rank in the line
+    busy = [(L.ptau_device_busy_ms(dev) - busy0) / 1e3 / dt]
+    if dist is not None:
+        allb = [None] * world
+        dist.all_gather_object(allb, busy[0])
+        busy = allb
     # the same step on the endomorphism path (membership asserted by the caller — what an operator that trusts its
     # coordinator's verifier runs): reported next to `value`, never as `value`
     endo = None
@@ -651,6 +658,7 @@ def main():
                        "baseline_config": args.config, "points_per_step_per_gpu": n, "device": name.value.decode(),
                        "parity": "bit-exact vs CPU oracle on %d sampled points" % sample},
             "roofline": roof,
+            "device_busy_frac_per_rank": busy,
             "cpu_baseline": base,
             "value_path": "BatchExpMode::Auto with CheckForCorrectness::No (the operator's contribute default): plain signed-window "
                           "multiplication, exact for ANY curve point",
@@ -776,6 +784,8 @@ def bench_verify(args, pkg, dev, rank, world, dist, backend, barrier):
         for k in range(args.warmup):
             step(k)
         barrier()
+        Lb = pkg.load_library()
+        busy0 = Lb.ptau_device_busy_ms(dev)
         t0 = time.perf_counter()
         dev_ms = sub_ms = 0.0
         for k in range(args.steps):
@@ -785,6 +795,11 @@ def bench_verify(args, pkg, dev, rank, world, dist, backend, barrier):
             sub_ms += tm["subgroup_ms"]
         barrier()
         dt = time.perf_counter() - t0
+        busy = [(Lb.ptau_device_busy_ms(dev) - busy0) / 1e3 / dt]
+        if dist is not None:
+            allb = [None] * world
+            dist.all_gather_object(allb, busy[0])
+            busy = allb
         if dist is not None:
             tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -805,6 +820,7 @@ def bench_verify(args, pkg, dev, rank, world, dist, backend, barrier):
                                        % (lg, elems, prm.accumulator_size, prm.contribution_size, base or "tmp"),
                            "baseline_config": 5, "elements_per_step_per_gpu": elems},
                 "device_resident": {"kernel_ms_per_chunk": dev_ms / args.steps, "chunks_per_s": 1e3 / (dev_ms / args.steps)},
+                "device_busy_frac_per_rank": busy,
                 "roofline": {"bound": "hbm", "kernel": "endo_subgroup_kernel (G1 x3 vectors + G2)", "kernel_ms": sub_ms / args.steps,
                              "achieved": algo / sub_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo / sub_s / 1e9 / HBM_PEAK_GBS,
                              "traffic": None, "note": "membership tests are ~126 doublings per element: integer-ALU-bound, see DESIGN.md"},
