@@ -37,6 +37,21 @@ PTAU_HD uint32_t lane_parity() {
     return 0;
 #endif
 }
+// A per-lane constant — c_lo in the even lane of a pair, c_hi in the odd lane — as ARITHMETIC on two instruction literals.
+// Written as a select of two table reads (hi ? C[H + j] : C[j]) the compiler turns it into ONE read through a selected
+// address: a vector memory load per limb per use, with its latency at the head of every product (five loads and a wait
+// per call, 14 per subtraction: 400 loads per window of the MNT kernels, profiles/r03_*).  mask = all ones in the odd lane.
+PTAU_HD uint32_t lane_hi_mask() { return 0u - lane_parity(); }
+// The same mask as a value the optimiser cannot see through: constants formed from it are rebuilt where they are used (two
+// cheap instructions per limb) instead of being hoisted out of the window loop and kept — i.e. spilled — across it.
+PTAU_HD uint32_t lane_hi_mask_here() {
+    uint32_t m = lane_hi_mask();
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(m));
+#endif
+    return m;
+}
+PTAU_HD uint32_t lane_const(uint32_t c_lo, uint32_t c_hi, uint32_t hi_mask) { return c_lo + ((c_hi - c_lo) & hi_mask); }
 PTAU_HD uint32_t lane_xchg(uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
@@ -82,10 +97,10 @@ struct FpL {
     PTAU_HD static bool hi_lane() { return lane_parity() != 0; }
     // this lane's half of a compile-time constant given as N limbs
     PTAU_HD static FpL load_const(const uint32_t *c) {
-        const bool hi = hi_lane();
+        const uint32_t hm = lane_hi_mask();
         FpL r;
 #pragma unroll
-        for (int j = 0; j < H; j++) r.l[j] = hi ? c[H + j] : c[j];
+        for (int j = 0; j < H; j++) r.l[j] = lane_const(c[j], c[H + j], hm);
         return r;
     }
     PTAU_HD static FpL zero() {
@@ -160,7 +175,7 @@ struct FpL {
 #pragma unroll
         for (int j = 0; j < H; j++) {
             const uint32_t ab = a.l[j] + b.l[j];                                   // < 2^30
-            const uint32_t pj = hi ? P::MOD[H + j] : P::MOD[j];
+            const uint32_t pj = lane_const(P::MOD[j], P::MOD[H + j], lane_hi_mask());
             const int32_t v = (int32_t)ab - (int32_t)pj + cy;
             cy = v >> LB;
             d[j] = (uint32_t)v & MASK;
@@ -198,7 +213,7 @@ struct FpL {
         uint32_t r[H];
 #pragma unroll
         for (int j = 0; j < H; j++) {
-            const uint32_t pj = hi ? P::MOD[H + j] : P::MOD[j];
+            const uint32_t pj = lane_const(P::MOD[j], P::MOD[H + j], lane_hi_mask());
             const uint32_t w = d[j] + (pj & mask) + c2;
             c2 = w >> LB;
             r[j] = w & MASK;
@@ -217,7 +232,7 @@ struct FpL {
         int32_t cy = 0;
 #pragma unroll
         for (int j = 0; j < H; j++) {
-            const uint32_t pj = hi ? P::MOD[H + j] : P::MOD[j];
+            const uint32_t pj = lane_const(P::MOD[j], P::MOD[H + j], lane_hi_mask());
             const int32_t v = (int32_t)(pj & nz) - (int32_t)a.l[j] + cy;
             cy = v >> LB;
             d[j] = (uint32_t)v & MASK;
@@ -289,7 +304,7 @@ struct FpL {
         const bool hi = hi_lane();
         uint32_t pm[H];
 #pragma unroll
-        for (int j = 0; j < H; j++) pm[j] = hi ? P::MOD[H + j] : P::MOD[j];
+        for (int j = 0; j < H; j++) pm[j] = lane_const(P::MOD[j], P::MOD[H + j], lane_hi_mask());
         uint64_t acc[H];
 #pragma unroll
         for (int j = 0; j < H; j++) acc[j] = 0;
@@ -369,7 +384,7 @@ struct FpL {
         uint32_t pm[H], az[H];
 #pragma unroll
         for (int j = 0; j < H; j++) {
-            pm[j] = hi ? P::MOD[H + j] : P::MOD[j];
+            pm[j] = lane_const(P::MOD[j], P::MOD[H + j], lane_hi_mask());
             az[j] = hi ? a[j] : 0u;        // the row of iterations i >= H: the even lane contributes nothing there
         }
         const uint32_t dbl_odd = hi ? 1u : 0u;
@@ -487,7 +502,7 @@ struct FpL {
         const bool hi = hi_lane();
         uint32_t pm[H], v[H];
 #pragma unroll
-        for (int j = 0; j < H; j++) pm[j] = hi ? P::MOD[H + j] : P::MOD[j];
+        for (int j = 0; j < H; j++) pm[j] = lane_const(P::MOD[j], P::MOD[H + j], lane_hi_mask());
         uint64_t c = 0;
 #pragma unroll
         for (int j = 0; j < H; j++) {

@@ -93,7 +93,7 @@ struct FpLZ {
         static constexpr Limbs v = make_subc(K, UB);
     };
     // this lane's half of a constant given as N limbs
-    PTAU_HD static uint32_t mine(const uint32_t *c, int j) { return hi_lane() ? c[H + j] : c[j]; }
+    PTAU_HD static uint32_t mine(const uint32_t *c, int j) { return lane_const(c[j], c[H + j], lane_hi_mask()); }
 
     template <int U1, int V1, int U2, int V2>
     PTAU_HD static E<U1 + U2, V1 + V2> add(const E<U1, V1> &a, const E<U2, V2> &b) {
@@ -104,20 +104,20 @@ struct FpLZ {
     }
     template <int U1, int V1, int U2, int V2>
     PTAU_HD static E<U1 + U2 + 2, V1 + subc_k(V2, U2 + 1)> sub(const E<U1, V1> &a, const E<U2, V2> &b) {
-        const bool hi = hi_lane();
+        const uint32_t hm = lane_hi_mask_here();
         constexpr int K = subc_k(V2, U2 + 1);
         E<U1 + U2 + 2, V1 + K> r;
 #pragma unroll
-        for (int i = 0; i < H; i++) r.l[i] = a.l[i] + (hi ? SubC<K, U2 + 1>::v.l[H + i] : SubC<K, U2 + 1>::v.l[i]) - b.l[i];
+        for (int i = 0; i < H; i++) r.l[i] = a.l[i] + lane_const(SubC<K, U2 + 1>::v.l[i], SubC<K, U2 + 1>::v.l[H + i], hm) - b.l[i];
         return r;
     }
     template <int U, int V>
     PTAU_HD static E<U + 2, subc_k(V, U + 1)> neg(const E<U, V> &a) {
-        const bool hi = hi_lane();
+        const uint32_t hm = lane_hi_mask_here();
         constexpr int K = subc_k(V, U + 1);
         E<U + 2, K> r;
 #pragma unroll
-        for (int i = 0; i < H; i++) r.l[i] = (hi ? SubC<K, U + 1>::v.l[H + i] : SubC<K, U + 1>::v.l[i]) - a.l[i];
+        for (int i = 0; i < H; i++) r.l[i] = lane_const(SubC<K, U + 1>::v.l[i], SubC<K, U + 1>::v.l[H + i], hm) - a.l[i];
         return r;
     }
     template <int K, int U, int V>
@@ -175,7 +175,7 @@ struct FpLZ {
         const bool hi = hi_lane();
         uint32_t pm[H];
 #pragma unroll
-        for (int j = 0; j < H; j++) pm[j] = hi ? P::MOD[H + j] : P::MOD[j];
+        for (int j = 0; j < H; j++) pm[j] = lane_const(P::MOD[j], P::MOD[H + j], lane_hi_mask());
         uint64_t acc[H];
 #pragma unroll
         for (int j = 0; j < H; j++) acc[j] = 0;
@@ -201,7 +201,7 @@ struct FpLZ {
         uint32_t pm[H], az[H];
 #pragma unroll
         for (int j = 0; j < H; j++) {
-            pm[j] = hi ? P::MOD[H + j] : P::MOD[j];
+            pm[j] = lane_const(P::MOD[j], P::MOD[H + j], lane_hi_mask());
             az[j] = hi ? a[j] : 0u;
         }
         const uint32_t dbl_odd = hi ? 1u : 0u;
@@ -248,7 +248,7 @@ struct FpLZ {
         const bool hi = hi_lane();
         uint32_t pm[H];
 #pragma unroll
-        for (int j = 0; j < H; j++) pm[j] = hi ? P::MOD[H + j] : P::MOD[j];
+        for (int j = 0; j < H; j++) pm[j] = lane_const(P::MOD[j], P::MOD[H + j], lane_hi_mask());
         uint64_t acc[H];
 #pragma unroll
         for (int j = 0; j < H; j++) acc[j] = 0;
