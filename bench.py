@@ -232,8 +232,8 @@ def whole_chunk_extras(pkg, curve, power, log2n, dev):
         dt2 = time.perf_counter() - t0
         out["verify_chunk_skip_ratio_check"] = {"seconds": dt2, "chunks_verified_per_s": 1.0 / dt2}
         modes = [("contribute_chunk_exact", pkg.BatchExpMode.Auto, "Auto, CheckForCorrectness::No (exact on any curve point: plain windows)")]
-        if not curve.startswith("mnt"):
-            modes.insert(0, ("contribute_chunk", verified, "Auto | INPUT_IN_SUBGROUP (challenge produced by the verification above: endomorphism path)"))
+        modes.insert(0, ("contribute_chunk", verified, "Auto | INPUT_IN_SUBGROUP (challenge produced by the verification above: endomorphism path"
+                                                       + (" — on the MNT curves that is GLS on the G2 vector; G1 has no endomorphism)" if curve.startswith("mnt") else ")")))
         for tag, mode, what in modes:
             if os.path.exists(f("r1")):
                 os.remove(f("r1"))
@@ -688,9 +688,10 @@ def main():
                      "alu_frac": (m2 * n2 / (t2["scalar_mul_ms"] / 1e3) / MAC_PEAK) if m2 else None, "macs_per_update": m2,
                      "path": "GLS after the membership probe (BatchExpMode::Auto)" if probed_endo else "plain windows",
                      "traffic_ratio": (p2["hbm_bytes_per_launch"] / (3 * cs2 * n2)) if p2 else None}
-            if not c2.startswith("mnt") and not args.exact_only:
+            if (not c2.startswith("mnt") or g2 == 2) and not args.exact_only:      # MNT: GLS on the twists (G2) only
                 run2(dc, 0, dr, 1, tau, ENDO)
                 entry["endomorphism_updates_per_s"] = n2 / (pkg.phase1_cli.last_timing(dev)["kernel_ms"] / 1e3)
+                entry["endomorphism_kernel_ms"] = pkg.phase1_cli.last_timing(dev)["scalar_mul_ms"]
             others["%s_G%d" % (c2, g2)] = entry
             del dc, dr
         if others:

@@ -296,6 +296,23 @@ def main():
             s.append("  static constexpr uint32_t PSI_CY[%d] = {%s};" % (n, limbs(pcy * R % p, n)))
             s.append("  static constexpr uint32_t PSI_N[%d] = {%s};   // |t - 1|, packed words" % (nwords, limbs(pn, nwords, 32)))
             s.append("  static constexpr bool PSI_NEG = %s;            // t - 1 < 0" % ("true" if pneg else "false"))
+            if fname.endswith("R29") and fname[:-3] in LAZY28_WIDE:
+                # GLS on the twist (k1_lazy_a.hpp): psi = [t - 1] on G2, so k = k0 + k1 N (N = |t - 1|, Euclidean split: both halves
+                # below 2^377) and k P = k0 P + k1 (+-psi(P)).  psi on a JACOBIAN entry: (CX X^q, CY Y^q, Z^q); Frobenius acts on
+                # coefficient j as a multiplication by F_j = NR^(j (q - 1) / deg) (F = (1, -1) for Fq2).  Per-coefficient constants
+                # in the carry-free field (28 limbs of 28 bits, R = 2^784), the sign of t - 1 folded into the Y row:
+                #   KX_j = CX F_j,   KY_j = +-CY F_j,   KZ_j = F_j
+                nz, Rz = 28, 1 << (28 * 28)
+                f1 = pow(nr % p, (p - 1) // deg, p)
+                F = [pow(f1, j, p) for j in range(deg)]
+                sgn = p - 1 if pneg else 1
+                rows = lambda vals: ",\n    ".join("{%s}" % limbs(v * Rz % p, nz, 28) for v in vals)
+                s.append("  static constexpr uint32_t PSI_KXZ[%d][%d] = {%s};" % (deg, nz, rows([pcx * f % p for f in F])))
+                s.append("  static constexpr uint32_t PSI_KYZ[%d][%d] = {%s};" % (deg, nz, rows([sgn * pcy * f % p for f in F])))
+                s.append("  static constexpr uint32_t PSI_KZZ[%d][%d] = {%s};" % (deg, nz, rows(F)))
+                assert pn.bit_length() <= 377 and pn.bit_length() > 352
+                s.append("  static constexpr uint32_t PSI_N12[12] = {%s};   // N = |t - 1|" % limbs(pn, 12, 32))
+                s.append("  static constexpr uint32_t PSI_RECIP[13] = {%s};   // floor(2^768 / N)" % limbs((1 << 768) // pn, 13, 32))
         s.append("  static constexpr int GLV_KIND = %d;   // 0 none, 1 half-size lambda (floor division), 2 lattice (Babai rounding)" % (1 if glv else (2 if glv2 else 0)))
         if glv2:
             # phi(x, y) = (BETA x, y) = LAMBDA (x, y); short basis (a1, b1), (a2, b2) of {(u, v): u + v LAMBDA = 0 mod r};

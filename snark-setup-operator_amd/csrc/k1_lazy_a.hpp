@@ -14,6 +14,7 @@ template <class FqP, class FrP, class Cfg>
 struct LazyAGroup {
     using P28 = typename LazyTwin<FqP>::type;
     using Z = FpLZ<P28>;
+    using CfgT = Cfg;
     static constexpr int DEG = Cfg::DEG;
     using K = std::conditional_t<DEG == 1, Fp1PZ<Z>, std::conditional_t<DEG == 2, Fp2QZ<Z, Cfg::NR>, Fp3HZ<Z, Cfg::NR>>>;
     static constexpr int LPP = 2 * DEG;                      // lanes per point
@@ -30,7 +31,45 @@ struct LazyAGroup {
     static constexpr int ENTRY_WORDS = 3 * H;                // one table entry of one lane: X | Y | Z
     static constexpr size_t WTAB_ENTRY_BYTES = (size_t)LPP * ENTRY_WORDS * 4;   // one table entry of one point
     static constexpr int POINTS_PER_BLOCK = DEG == 3 ? 4 * 10 : 256 / LPP;
+    // GLS on the twist: psi = twist o Frobenius o untwist acts as [t - 1] on G2 (gen_constants.py PSI_*): two 377-bit halves
+    static constexpr bool HAS_GLS = Cfg::PSI_KIND == 1 && DEG >= 2;
 };
+
+// k = k0 + k1 N for N = |t - 1| (12 words), k below the group order (24 words): k1 = floor(k / N) through the reciprocal
+// floor(2^768 / N), at most three corrections; both halves below 2^377.  Valid use: points of the prime-order subgroup only.
+template <class Cfg>
+__device__ inline void gls2_split(const uint32_t (&k)[24], uint32_t (&k0)[12], uint32_t (&k1)[12]) {
+    uint32_t rc[13], nn[12];
+#pragma unroll
+    for (int t = 0; t < 13; t++) rc[t] = Cfg::PSI_RECIP[t];
+#pragma unroll
+    for (int t = 0; t < 12; t++) nn[t] = Cfg::PSI_N12[t];
+    uint32_t prod[37];
+    bn_mul<24, 13>(k, rc, prod);
+    uint32_t q[13];
+#pragma unroll
+    for (int t = 0; t < 13; t++) q[t] = prod[24 + t];
+    uint32_t qn[25];
+    bn_mul<13, 12>(q, nn, qn);
+    uint32_t rem[13];
+    uint32_t br = 0;
+#pragma unroll
+    for (int t = 0; t < 13; t++) rem[t] = subb(k[t], qn[t], br);
+    for (int it = 0; it < 4; it++) {
+        uint32_t tt[13];
+        uint32_t b2 = 0;
+#pragma unroll
+        for (int t = 0; t < 13; t++) tt[t] = subb(rem[t], t < 12 ? nn[t] : 0u, b2);
+        if (b2) break;   // rem < N
+#pragma unroll
+        for (int t = 0; t < 13; t++) rem[t] = tt[t];
+        uint32_t c = 1;
+#pragma unroll
+        for (int t = 0; t < 13; t++) q[t] = addc(q[t], 0u, c);
+    }
+#pragma unroll
+    for (int t = 0; t < 12; t++) { k0[t] = rem[t]; k1[t] = q[t]; }
+}
 
 // One base-field coefficient from its canonical little-endian bytes straight into the carry-free Montgomery form of the
 // lane pair: both lanes read the bytes, test value < p on the packed words, cut their own 14 limbs of 28 bits and multiply by
@@ -89,13 +128,14 @@ __device__ inline bool lazy_a_point(uint64_t n, uint64_t &i) {
 template <class LG>
 __device__ inline int window_scalar_mul_lazy_a_thread(const uint8_t *__restrict__ in, uint32_t *__restrict__ scratch,
                                                       uint32_t *__restrict__ wtab, uint64_t n, uint64_t i, const ScalarSource &src,
-                                                      int check_input) {
+                                                      int check_input, int use_gls) {
     using K = typename LG::K;
     using Z = typename LG::Z;
     using Acc = typename LG::Acc;
     using CT = typename LG::CT;
     using L29 = typename LG::L29;
     using Fr = typename LG::Fr;
+    using Cfg_ = typename LG::CfgT;
     constexpr int D = LG::DEG, H = LG::H, NL = Fr::N, NW = NL * 8;
     static_assert(Fr::Params::BITS <= 32 * NL - 3, "scalar field leaves no headroom for the digit offset");
     const uint32_t j = K::coef(), hi = lane_parity();
@@ -165,6 +205,42 @@ __device__ inline int window_scalar_mul_lazy_a_thread(const uint8_t *__restrict_
         }
         PTAU_HD CT z() const { return load(2); }
     };
+    // psi of a table entry, formed where the formula uses it: coefficient j of X, Y, Z times KX_j, KY_j, KZ_j (Frobenius and the
+    // twist constants in one base product per coordinate; the sign of t - 1 sits in KY)
+    struct FromTablePsi {
+        const uint32_t *e;
+        bool negate;
+        PTAU_HD CT load(int c) const {
+            CT v;
+            const volatile uint32_t *w = e + c * H;
+#pragma unroll
+            for (int t = 0; t < H; t++) K::raw(v).l[t] = w[t];
+            return v;
+        }
+        PTAU_HD static CT times_row(const CT &v, const uint32_t (*tbl)[2 * H]) {
+            const uint32_t *row = &tbl[K::coef()][lane_parity() ? H : 0];
+            typename Z::template E<1, 1> c;
+#pragma unroll
+            for (int t = 0; t < H; t++) c.l[t] = row[t];
+            return K::wrap(Z::mul(K::raw(v), c));
+        }
+        PTAU_HD CT x() const {
+            if constexpr (LG::HAS_GLS) return times_row(load(0), Cfg_::PSI_KXZ);
+            else return load(0);
+        }
+        PTAU_HD auto y() const {
+            CT v = load(1);
+            if constexpr (LG::HAS_GLS) v = times_row(v, Cfg_::PSI_KYZ);
+            const auto nv = K::neg(v);
+            decltype(K::neg(v)) r = v;
+            if (negate) r = nv;
+            return r;
+        }
+        PTAU_HD CT z() const {
+            if constexpr (LG::HAS_GLS) return times_row(load(2), Cfg_::PSI_KZZ);
+            else return load(2);
+        }
+    };
     {
         Acc cur = {px, py, pz};
         store_entry(0, cur);
@@ -177,10 +253,49 @@ __device__ inline int window_scalar_mul_lazy_a_thread(const uint8_t *__restrict_
     // ---- signed 4-bit windows, MSB first ----
     uint32_t k[NL];
     thread_scalar<Fr>(src, i, k);
+    Acc acc = Acc::infinity();
+    if constexpr (LG::HAS_GLS && NL == 24) {
+        if (use_gls) {
+            // k P = k0 P + k1 (+-psi(P)): two 377-bit halves over ONE table, interleaved signed 4-bit windows, psi applied to the
+            // entry on the fly (three base products) — half the doublings.  Only for points of the prime-order subgroup.
+            uint32_t kk[2][12];
+            gls2_split<Cfg_>(k, kk[0], kk[1]);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                uint32_t c2 = 0;
+#pragma unroll
+                for (int t = 0; t < 12; t++) kk[h][t] = addc(kk[h][t], 0x88888888u, c2);   // halves < 2^377: no carry out of 384 bits
+            }
+            for (int w = 12 * 8 - 1; w >= 0; w--) {
+                if (!acc.is_inf()) {
+#pragma nounroll
+                    for (int d = 0; d < WINDOW_BITS; d++) acc = Acc::dbl(acc);
+                }
+#pragma nounroll
+                for (int h = 0; h < 2; h++) {
+                    uint32_t limb = 0;
+#pragma unroll
+                    for (int t = 0; t < 12; t++) limb = (t == (w >> 3)) ? (h ? kk[1][t] : kk[0][t]) : limb;
+                    const int dgt = (int)((limb >> ((w & 7) * 4)) & 15u) - 8;
+                    if (dgt != 0) {
+                        const int mag = dgt < 0 ? -dgt : dgt;
+                        const FromTable ent{entry(mag - 1), dgt < 0};
+                        if (!K::limbs_all_zero(ent.z())) {   // the multiple is not O
+                            if (h == 0) acc = Acc::add(acc, ent);
+                            else acc = Acc::add(acc, FromTablePsi{entry(mag - 1), dgt < 0});
+                        }
+                    }
+                }
+            }
+            put29(Z::to29(K::raw(acc.X)), 0);
+            put29(Z::to29(K::raw(acc.Y)), 1);
+            put29(Z::to29(K::raw(acc.Zc)), 2);
+            return 0;
+        }
+    }
     uint32_t cy = 0;
 #pragma unroll
     for (int t = 0; t < NL; t++) k[t] = addc(k[t], 0x88888888u, cy);
-    Acc acc = Acc::infinity();
     for (int w = NW - 1; w >= 0; w--) {
         if (!acc.is_inf()) {
 #pragma nounroll
@@ -206,10 +321,10 @@ __device__ inline int window_scalar_mul_lazy_a_thread(const uint8_t *__restrict_
 template <class LG>
 __global__ void __launch_bounds__(256, 2)
 window_scalar_mul_lazy_a_kernel(const uint8_t *__restrict__ in, uint32_t *__restrict__ scratch, uint32_t *__restrict__ wtab,
-                                uint64_t n, ScalarSource src, int check_input, int *__restrict__ err) {
+                                uint64_t n, ScalarSource src, int check_input, int use_gls, int *__restrict__ err) {
     uint64_t i;
     if (!lazy_a_point<LG>(n, i)) return;
-    const int bad = window_scalar_mul_lazy_a_thread<LG>(in, scratch, wtab, n, i, src, check_input);
+    const int bad = window_scalar_mul_lazy_a_thread<LG>(in, scratch, wtab, n, i, src, check_input, use_gls);
     if (bad) atomicOr(err, bad);
 }
 

@@ -1575,7 +1575,7 @@ struct Launch {
             if (!cin && lazy_a_enabled()) {   // 2 / 4 / 6 lanes per point; results land in G's Jacobian layout
                 const uint64_t blocks = (n + GA::POINTS_PER_BLOCK - 1) / GA::POINTS_PER_BLOCK;
                 hipLaunchKernelGGL(window_scalar_mul_lazy_a_kernel<GA>, dim3((unsigned)blocks), dim3(256), 0, s, in, (uint32_t *)scratch,
-                                   (uint32_t *)wtab, n, src, check_input, err);
+                                   (uint32_t *)wtab, n, src, check_input, src.mode == SCALAR_TAU_TABLE ? use_glv : 0, err);
                 return;
             }
         }

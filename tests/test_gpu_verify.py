@@ -377,7 +377,7 @@ def test_e2e_phase1_config1_files(pkg, cref, tmp_path):
     assert combined[64 + 96:64 + 192] == serde.write_point(G1, G1.mul(G1.gen, t), False)
 
 
-@pytest.mark.parametrize("name,group", [("bls12_377", 1), ("bls12_377", 2), ("bw6", 1), ("bw6", 2)])
+@pytest.mark.parametrize("name,group", [("bls12_377", 1), ("bls12_377", 2), ("bw6", 1), ("bw6", 2), ("mnt4_753", 2), ("mnt6_753", 2)])
 def test_batch_exp_exact_on_any_curve_point(name, group, pkg, cref):
     """arkworks' batch_exp returns [k]P for ANY curve point, and contribute's default is CheckForCorrectness::No
     (contribute.rs:816-819): with unchecked input the update must be exact on points OUTSIDE the prime-order subgroup too,
@@ -412,7 +412,7 @@ def test_batch_exp_exact_on_any_curve_point(name, group, pkg, cref):
     assert e.value.code == -1
 
 
-@pytest.mark.parametrize("name,group", [("bls12_377", 1), ("bls12_377", 2), ("bw6", 1)])
+@pytest.mark.parametrize("name,group", [("bls12_377", 1), ("bls12_377", 2), ("bw6", 1), ("mnt4_753", 2), ("mnt6_753", 2)])
 def test_contribute_check_input_in_group(name, group, pkg, cref):
     """CheckForCorrectness on the contribute side (--force-correctness-checks upgrades it to Full, contribute.rs:129-133):
     OnlyInGroup / Full run the membership test over the input vector before the update and reject a curve point outside
