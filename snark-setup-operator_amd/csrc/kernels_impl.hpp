@@ -1460,6 +1460,135 @@ decompress_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, uin
     if (bad) atomicOr(err, bad);
 }
 
+// ---- A/B variant (north_star wording: "window tables staged in LDS"): K1 of a one-lane carry-free G1 group with the per-point
+// window table in LDS.  160 KB of LDS per CU hold at most a FOUR-entry table (1P..4P, common Z: 2 x 14 limbs per entry) for
+// the 256 resident lanes of ONE wave per SIMD, so the windows are 3 bits (85 windows: 252 doublings + ~74 additions instead of
+// 252 + 60).  Selected by PTAU_AB_LDS_TABLE=1 for BatchExpMode exact-path launches; measured against the HBM table in
+// profiles/r03_ab_lds_table.txt — it is NOT the product path.
+template <class G>
+__global__ void __launch_bounds__(256, 1)
+window_scalar_mul_lds_table_kernel(const uint8_t *__restrict__ in, typename G::J *__restrict__ scratch, uint64_t n,
+                                   ScalarSource src, int check_input, int *__restrict__ err) {
+    using Fr = typename G::Fr;
+    using A = typename G::A;
+    using J = typename G::J;
+    using L = LazyOf<G>;
+    using K = typename L::K;
+    using AccT = typename L::Acc;
+    using KM = typename LoopAcc<G, true>::zc_type;
+    constexpr int NL = Fr::N, E3 = 4, NW3 = 85;
+    static_assert(G::LANE_MODE == LANES_ONE && G::F::DEG == 1 && NL == 8 && L::N == 14, "written for BLS12-377 G1");
+    __shared__ uint32_t tab[E3 * 2 * L::N * 256];   // [entry][coordinate word][lane]: conflict-free
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    A p;
+    int bad = read_point_any<G>(in, 0, i, p);
+    if ((check_input & 1) && p.inf) bad |= ERRBIT_INFINITY;
+    if (bad || p.inf) {
+        store_jac<G>(scratch, i, J::infinity());
+        if (bad) atomicOr(err, bad);
+        return;
+    }
+    auto slot = [&](int e, int w) -> uint32_t & { return tab[((e * 2 * L::N) + w) * 256 + threadIdx.x]; };
+    auto st = [&](int e, int c, const auto &v) {
+#pragma unroll
+        for (int j = 0; j < L::N; j++) slot(e, c * L::N + j) = v.l[j];
+    };
+    auto ld = [&](int e, int c) {
+        KM v;
+#pragma unroll
+        for (int j = 0; j < L::N; j++) v.l[j] = slot(e, c * L::N + j);
+        return v;
+    };
+    const typename L::C px = L::to_lazy(p.x), py = L::to_lazy(p.y);
+    const typename L::AX pxa = px;
+    const typename L::AY pya = py;
+    AccT cur = {px, py, K::one()};
+    decltype(cur.Zc) zs[E3 - 1];
+    KM pre[E3 - 1];
+    KM zl = K::one();
+#pragma unroll
+    for (int e = 1; e < E3; e++) {
+        cur = AccT::add_mixed(cur, pxa, pya);
+        st(e, 0, cur.X);
+        st(e, 1, cur.Y);
+        zs[e - 1] = cur.Zc;
+        pre[e - 1] = zl;
+        if (!K::is_zero(cur.Zc)) zl = K::mul(zl, cur.Zc);
+    }
+    KM suf = K::one();
+#pragma unroll
+    for (int e = E3 - 1; e >= 1; e--) {
+        const auto ze = zs[e - 1];
+        if (K::is_zero(ze)) {
+            st(e, 0, K::zero());
+            st(e, 1, K::zero());
+        } else {
+            const KM c = K::mul(pre[e - 1], suf);
+            suf = K::mul(suf, ze);
+            const auto c2 = K::sqr(c);
+            st(e, 0, KM(K::mul(decltype(cur.X)(ld(e, 0)), c2)));
+            st(e, 1, KM(K::mul(decltype(cur.Y)(ld(e, 1)), K::mul(c2, c))));
+        }
+    }
+    const KM zcz = zl;
+    {
+        const auto c2 = K::sqr(zcz);
+        st(0, 0, KM(K::mul(px, c2)));
+        st(0, 1, KM(K::mul(py, K::mul(c2, zcz))));
+    }
+    // signed 3-bit digits: k + sum_w 4 8^w, digit_w = ((k' >> 3w) & 7) - 4 in [-4, 3]
+    uint32_t k[NL];
+    thread_scalar<Fr>(src, i, k);
+    {
+        uint32_t cy = 0;
+#pragma unroll
+        for (int j = 0; j < NL; j++) {
+            uint32_t c = 0;
+            for (int w = 0; w < NW3; w++) {
+                const int b = 3 * w + 2;
+                if (b >= 32 * j && b < 32 * j + 32) c |= 1u << (b - 32 * j);
+            }
+            k[j] = addc(k[j], c, cy);
+        }
+    }
+    AccT acc = AccT::infinity();
+    for (int w = NW3 - 1; w >= 0; w--) {
+        if (!acc.is_inf()) {
+#pragma nounroll
+            for (int d = 0; d < 3; d++) acc = AccT::dbl(acc);
+        }
+        const int bit = 3 * w, li = bit >> 5, sh = bit & 31;
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int j = 0; j < NL; j++) {
+            lo = (j == li) ? k[j] : lo;
+            hi = (j == li + 1) ? k[j] : hi;
+        }
+        const int dgt = (int)((uint32_t)((((uint64_t)hi << 32) | lo) >> sh) & 7u) - 4;
+        if (dgt != 0) {
+            const int mag = dgt < 0 ? -dgt : dgt;
+            typename L::AX x = ld(mag - 1, 0);
+            const KM y = ld(mag - 1, 1);
+            if (!(K::limbs_all_zero(x) && K::limbs_all_zero(y))) {
+                typename L::AY ys = y;
+                if (dgt < 0) ys = K::neg(y);
+                acc = AccT::add_mixed(acc, x, ys);
+            }
+        }
+    }
+    const auto z = K::mul(acc.Zc, zcz);
+    store_jac<G>(scratch, i, J{L::from_lazy(acc.X), L::from_lazy(acc.Y), L::from_lazy(z)});
+}
+
+inline bool ab_lds_table_enabled() {
+    static const bool v = [] {
+        const char *e = getenv("PTAU_AB_LDS_TABLE");
+        return e && e[0] == '1';
+    }();
+    return v;
+}
+
 }  // namespace ptau
 #include "k1_lazy_a.hpp"
 namespace ptau {
@@ -1583,6 +1712,13 @@ struct Launch {
             if (!cin && lane_pair_enabled()) {   // two threads per point; results land in G's Jacobian layout
                 hipLaunchKernelGGL((window_scalar_mul_kernel<GL, 0>), grid(n * 2), dim3(256), 0, s, in, (typename GL::J *)scratch,
                                    (typename GL::J *)wtab, n, src, check_input, use_glv, err);
+                return;
+            }
+        }
+        if constexpr (G::LAZY_LOOP && G::LANE_MODE == LANES_ONE && G::F::DEG == 1 && Fr::N == 8) {
+            if (!cin && !use_glv && src.mode != SCALAR_SUBGROUP_ENDO && ab_lds_table_enabled()) {   // A/B only (see the kernel)
+                hipLaunchKernelGGL(window_scalar_mul_lds_table_kernel<G>, grid(n), dim3(256), 0, s, in, (typename G::J *)scratch, n, src,
+                                   check_input, err);
                 return;
             }
         }

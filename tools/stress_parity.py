@@ -14,7 +14,11 @@ from oracle.pyref.ec import Group
 pkg = load_package()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 rng = random.Random(2026)
-for name, group in (("bls12_377", 1), ("bls12_377", 2), ("bw6", 1), ("bw6", 2)):
+n_arg = n
+# the MNT groups (round 3: carry-free lane-per-coefficient kernels, GLS on the twists) at sizes the CPU oracle finishes in seconds
+for name, group, div in (("bls12_377", 1, 1), ("bls12_377", 2, 1), ("bw6", 1, 1), ("bw6", 2, 1), ("mnt4_753", 1, 8), ("mnt6_753", 1, 8),
+                         ("mnt4_753", 2, 16), ("mnt6_753", 2, 32)):
+    n = max(64, n_arg // div)
     c = CURVES[name]; G = Group(c, group); F = G.F
     def curve_point():
         while True:
