@@ -38,7 +38,7 @@ struct LazyAGroup {
 // k = k0 + k1 N for N = |t - 1| (12 words), k below the group order (24 words): k1 = floor(k / N) through the reciprocal
 // floor(2^768 / N), at most three corrections; both halves below 2^377.  Valid use: points of the prime-order subgroup only.
 template <class Cfg>
-__device__ inline void gls2_split(const uint32_t (&k)[24], uint32_t (&k0)[12], uint32_t (&k1)[12]) {
+PTAU_HD inline void gls2_split(const uint32_t (&k)[24], uint32_t (&k0)[12], uint32_t (&k1)[12]) {
     uint32_t rc[13], nn[12];
 #pragma unroll
     for (int t = 0; t < 13; t++) rc[t] = Cfg::PSI_RECIP[t];

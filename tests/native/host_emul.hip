@@ -7,6 +7,8 @@
 //        field : base-field arithmetic of the group's Fq class.  stdin = n pairs (a, b) of canonical BYTES-long elements;
 //               stdout per pair: a+b | a-b | a*b | a^2 | -a | 1/a (0 for a = 0) | sqrt flag byte + root (0 when none) | sign byte
 //        fieldz: the same input; arithmetic of the carry-free twin field (fpz.hpp), see the op
+//        gls2split: MNT twists only.  <n> = 0, <start> = the number of scalars; stdin = scalars x 24 u32 words; stdout per scalar: k0 (12 words) | k1 (12 words) of the
+//               Euclidean split k = k0 + k1 |t - 1| K1's GLS loop consumes (k1_lazy_a.hpp)
 //        subgroup : stdin = n points; stdout = n bytes of error bits (0 = in the prime-order subgroup)
 //        msm  : stdin = n points (uncompressed) then n x Fr::N u32 scalar limbs; <start> = window bits c (0 = the
 //               library's own plan), <cout> = 1 adds the shifted sum (needs n + 1 points); stdout = 1 or 2 points
@@ -76,13 +78,13 @@ static int run(const std::string &op, uint64_t n, uint64_t start, int cin, int c
             const int B = Fq::BYTES;
             in.resize(n * 2 * B);
             if (fread(in.data() + n * isz, 1, in.size() - n * isz, stdin) != in.size() - n * isz && in.size() > n * isz) return 2;
-            out.assign(n * (7 * B + 1), 0);
+            out.assign(n * (8 * B + 1), 0);
             for (uint64_t i = 0; i < n; i++) {
                 Fq a29, b29;
                 uint8_t fl = 0;
                 if (!Fq::read_bytes(in.data() + (2 * i) * B, false, &fl, a29) || !Fq::read_bytes(in.data() + (2 * i + 1) * B, false, &fl, b29)) return 5;
                 const auto a = Z::from29(a29), b = Z::from29(b29);
-                uint8_t *o = out.data() + i * (7 * B + 1);
+                uint8_t *o = out.data() + i * (8 * B + 1);
                 Z::to29(Z::add(a, b)).write_bytes(o, 0);
                 Z::to29(Z::sub(a, b)).write_bytes(o + B, 0);
                 Z::to29(Z::mul(a, b)).write_bytes(o + 2 * B, 0);
@@ -93,6 +95,18 @@ static int run(const std::string &op, uint64_t n, uint64_t start, int cin, int c
                 const auto s1 = Z::norm(Z::add(Z::template times<8>(a), Z::template times<4>(b)));          // < 24 p
                 const auto big = Z::norm(Z::sub(Z::norm(Z::template times<8>(s1)), Z::template times<2>(a)));  // < 197 p
                 Z::to29(Z::vreduce(big)).write_bytes(o + 6 * B, 0);
+                {
+                    // the fused Fq2 coefficient a0 b0 + 5 (KN p - a1) b1 with a0 = a1 = a, b0 = b1 = b: limbs of the second
+                    // operand up to 15 x 2^28 (three units x 5), the column sums of both products share one reduction
+                    uint32_t x2[Z::N];
+                    typename Z::template E<1, 2> r2;
+                    for (int j = 0; j < Z::N; j++) {
+                        const uint32_t ng = Z::template SubC<32, 2>::v.l[j] - a.l[j];
+                        x2[j] = (ng << 2) + ng;
+                    }
+                    Z::ps_mul2(a.l, b.l, x2, b.l, r2.l);
+                    Z::to29(r2).write_bytes(o + 7 * B, 0);
+                }
                 uint8_t f = 0;
                 f |= Z::is_zero(Z::norm(Z::sub(a, a))) ? 1 : 0;
                 f |= Z::is_zero(Z::norm(Z::sub(a, b))) ? 2 : 0;
@@ -100,9 +114,27 @@ static int run(const std::string &op, uint64_t n, uint64_t start, int cin, int c
                 for (int j = 0; j < Z::N; j++) kp.l[j] = Z::template SubC<33, 0>::v.l[j];   // 33 p, plain limbs
                 f |= Z::is_zero(kp) ? 4 : 0;
                 f |= Z::is_zero(a) ? 8 : 0;
-                o[7 * B] = f;
+                o[8 * B] = f;
             }
             fwrite(out.data(), 1, out.size(), stdout);
+            return 0;
+        } else {
+            return 6;
+        }
+    }
+    if (op == "gls2split") {
+        if constexpr (G::J::CfgT::PSI_KIND == 1 && G::Fr::N == 24) {
+            // <n> = 0 (no points to read), the scalar count travels in <start>
+            const uint64_t ns = start;
+            std::vector<uint32_t> k32(ns * 24), o32(ns * 24);
+            if (ns && fread(k32.data(), 4, k32.size(), stdin) != k32.size()) return 2;
+            for (uint64_t i = 0; i < ns; i++) {
+                uint32_t k[24], k0[12], k1[12];
+                for (int t = 0; t < 24; t++) k[t] = k32[i * 24 + t];
+                gls2_split<typename G::J::CfgT>(k, k0, k1);
+                for (int t = 0; t < 12; t++) { o32[i * 24 + t] = k0[t]; o32[i * 24 + 12 + t] = k1[t]; }
+            }
+            fwrite(o32.data(), 4, o32.size(), stdout);
             return 0;
         } else {
             return 6;

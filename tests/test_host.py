@@ -367,7 +367,7 @@ def test_carry_free_field_arithmetic_on_host():
     data = b"".join(a.to_bytes(B, "little") + b.to_bytes(B, "little") for a, b in vals)
     r = subprocess.run([exe, "fieldz", "0", "1", str(len(vals)), "0", "0", "0", "0", "-"], input=data, capture_output=True)
     assert r.returncode == 0, r.returncode
-    rec = 7 * B + 1
+    rec = 8 * B + 1
     assert len(r.stdout) == rec * len(vals)
     for i, (a, b) in enumerate(vals):
         o = r.stdout[i * rec:(i + 1) * rec]
@@ -375,7 +375,44 @@ def test_carry_free_field_arithmetic_on_host():
         assert g(0) == (a + b) % p and g(1) == (a - b) % p and g(2) == a * b % p and g(3) == a * a % p and g(4) == (-a) % p
         assert g(5) == (5 * a - 8 * b) % p
         assert g(6) == (62 * a + 32 * b) % p
-        assert o[7 * B] == (1 | (2 if a == b else 0) | 4 | (8 if a == 0 else 0)), (a, b, o[7 * B])
+        assert g(7) == (-4 * a * b) % p, (a, b)      # a b + 5 (32 p - a) b: two products, one reduction (ps_mul2)
+        assert o[8 * B] == (1 | (2 if a == b else 0) | 4 | (8 if a == 0 else 0)), (a, b, o[8 * B])
+
+
+@pytest.mark.parametrize("curve", ["mnt4_753", "mnt6_753"])
+def test_gls_scalar_split_on_host(curve):
+    """k1_lazy_a.hpp's gls2_split (the Euclidean split k = k0 + k1 N, N = |t - 1|, of K1's GLS loop on the MNT twists, through
+    the reciprocal floor(2^768 / N) and at most three corrections): exact recomposition, both halves in range, on edge scalars
+    (0, r - 1, multiples of N and their neighbours, all-ones words) and random ones."""
+    import random
+    exe = os.path.join(ROOT, "tests", "native", "host_emul")
+    if not os.path.exists(exe):
+        pytest.skip("host_emul not built")
+    cv = CURVES[curve]
+    r_ = cv.r
+    # N from the generated constants (the twist's Frobenius eigenvalue is t - 1 modulo r)
+    import re
+    inc = open(os.path.join(ROOT, "snark-setup-operator_amd", "csrc", "curve_constants.inc")).read()
+    tag = "Mnt4G2Cfg" if curve == "mnt4_753" else "Mnt6G2Cfg"
+    body = inc[inc.index("struct " + tag):]
+    m = re.search(r"PSI_N12\[12\]\s*=\s*\{([^}]*)\}", body)
+    words = [int(w.strip().rstrip("u"), 0) for w in m.group(1).split(",") if w.strip()]
+    N = sum(w << (32 * i) for i, w in enumerate(words))
+    assert 1 << 376 <= N < 1 << 377
+    rng = random.Random(5)
+    ks = [0, 1, 2, N - 1, N, N + 1, 2 * N - 1, 2 * N, r_ - 1, r_ - 2, (r_ // N) * N, (r_ // N) * N - 1, (r_ // N) * N + 1 if (r_ // N) * N + 1 < r_ else 0,
+          (1 << 752) - 1 if (1 << 752) - 1 < r_ else (1 << 751) - 1, int("ffffffff" * 23, 16) % r_]
+    ks += [rng.randrange(r_) for _ in range(2000)]
+    ks += [q * N + d for q in (rng.randrange(r_ // N) for _ in range(200)) for d in (0, 1, N - 1)]
+    data = b"".join(k.to_bytes(96, "little") for k in ks)
+    cid = "2" if curve == "mnt4_753" else "3"
+    r = subprocess.run([exe, "gls2split", cid, "2", "0", str(len(ks)), "0", "0", "0", "-"], input=data, capture_output=True)
+    assert r.returncode == 0, r.returncode
+    assert len(r.stdout) == 96 * len(ks)
+    for i, k in enumerate(ks):
+        k0 = int.from_bytes(r.stdout[96 * i:96 * i + 48], "little")
+        k1 = int.from_bytes(r.stdout[96 * i + 48:96 * i + 96], "little")
+        assert k0 < N and k1 < 1 << 377 and k0 + k1 * N == k, (hex(k), hex(k0), hex(k1))
 
 
 def test_file_level_tail_argument_checks_without_gpu(pkg, tmp_path):
