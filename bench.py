@@ -788,12 +788,15 @@ def bench_verify(args, pkg, dev, rank, world, dist, backend, barrier):
         Lb = pkg.load_library()
         busy0 = Lb.ptau_device_busy_ms(dev)
         t0 = time.perf_counter()
-        dev_ms = sub_ms = 0.0
+        dev_ms = sub_ms = dec_ms = msm_ms = tail_ms = 0.0
         for k in range(args.steps):
             step(k)
             tm = pkg.phase1_cli.last_timing(dev)
             dev_ms += tm["kernel_ms"]
             sub_ms += tm["subgroup_ms"]
+            dec_ms += tm["decompress_ms"]
+            msm_ms += tm["msm_ms"]
+            tail_ms += tm["msm_tail_ms"]
         barrier()
         dt = time.perf_counter() - t0
         busy = [(Lb.ptau_device_busy_ms(dev) - busy0) / 1e3 / dt]
@@ -809,8 +812,8 @@ def bench_verify(args, pkg, dev, rank, world, dist, backend, barrier):
         if rank == 0:
             assert open(f("c1"), "rb").read(64) == open(f("v.r.hash"), "rb").read()
             elems = 4 * n + 1
-            sub_s = sub_ms / args.steps / 1e3
-            algo = 3 * n * 96 + (n + 1) * 192      # the membership kernels read every decompressed element once
+            dec_s = dec_ms / args.steps / 1e3
+            algo = 3 * n * (48 + 96) + (n + 1) * (96 + 192)      # decompression: compressed element in, uncompressed element out
             print(json.dumps({
                 "metric": "chunks verified/sec", "value": world * args.steps / dt, "unit": "chunks verified/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -820,11 +823,16 @@ def bench_verify(args, pkg, dev, rank, world, dist, backend, barrier):
                                        "PCIe and the BLAKE2b chain are inside the step (the path's boundary is the file pair)"
                                        % (lg, elems, prm.accumulator_size, prm.contribution_size, base or "tmp"),
                            "baseline_config": 5, "elements_per_step_per_gpu": elems},
-                "device_resident": {"kernel_ms_per_chunk": dev_ms / args.steps, "chunks_per_s": 1e3 / (dev_ms / args.steps)},
+                "device_resident": {"kernel_ms_per_chunk": dev_ms / args.steps, "chunks_per_s": 1e3 / (dev_ms / args.steps),
+                                    "decompress_ms": dec_ms / args.steps, "subgroup_ms": sub_ms / args.steps, "msm_ms": msm_ms / args.steps,
+                                    "msm_tail_latency_ms_hidden_on_second_stream": tail_ms / args.steps,
+                                    "note": "SubgroupCheckMode::Auto on 2^20 elements = the batched membership test through the buckets of "
+                                            "the ratio check's MSM (inside msm_ms); PTAU_BATCHED_SUBGROUP=0 runs the exact per-element test"},
                 "device_busy_frac_per_rank": busy,
-                "roofline": {"bound": "hbm", "kernel": "endo_subgroup_kernel (G1 x3 vectors + G2)", "kernel_ms": sub_ms / args.steps,
-                             "achieved": algo / sub_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo / sub_s / 1e9 / HBM_PEAK_GBS,
-                             "traffic": None, "note": "membership tests are ~126 doublings per element: integer-ALU-bound, see DESIGN.md"},
+                "roofline": {"bound": "hbm", "kernel": "decompress_kernel (G1 x3 vectors + G2)", "kernel_ms": dec_ms / args.steps,
+                             "achieved": algo / dec_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo / dec_s / 1e9 / HBM_PEAK_GBS,
+                             "traffic": None, "note": "a square root is ~575 field products per coordinate (331-bit exponentiation + "
+                                                      "Pohlig-Hellman in the 2^46 torsion): integer-ALU-bound, see DESIGN.md"},
                 "sharded_transform_ratios": sharded,
                 "cpu_baseline": cpu_verify_baseline(lg) if world == 1 else None}))
     finally:

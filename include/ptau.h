@@ -38,8 +38,17 @@ enum { PTAU_MODE_CHUNKED = 0, PTAU_MODE_FULL = 1 };
 enum { PTAU_PROVING_GROTH16 = 0, PTAU_PROVING_MARLIN = 1 };
 /* setup_utils::CheckForCorrectness — src/bin/contribute.rs:38-43,816-819,971-980 */
 enum { PTAU_CHECK_NO = 0, PTAU_CHECK_ONLY_NON_ZERO = 1, PTAU_CHECK_ONLY_IN_GROUP = 2, PTAU_CHECK_FULL = 3 };
-/* setup_utils::SubgroupCheckMode — src/bin/contribute.rs:140-145.  AUTO, DIRECT and BATCHED all run the EXACT per-element
- * membership test (endomorphism test on BLS12-377, [r]P == O elsewhere): same accept/reject set as Direct. */
+/* setup_utils::SubgroupCheckMode — src/bin/contribute.rs:140-145.
+ *   DIRECT  : the exact per-element membership test (endomorphism tests on BLS12-377 / BW6-761 / the MNT twists — same
+ *             accept/reject set as [r]P == O);
+ *   BATCHED, and AUTO on more than 2^12 elements (setup-utils check_subgroup: BATCH_SIZE = 1 << 12): the batched test with
+ *             SECURITY_PARAM = 128 — random bucket sums, each tested exactly; a vector holding an element outside the subgroup
+ *             passes with probability < 2^-128.  Here the buckets are those of the power-ratio check's own random linear
+ *             combination (ptau_verify_chunk / transform_pok_and_correctness with ratio_check != 0), so the test rides on work
+ *             already done; without a ratio check, on vectors of <= 2^12 elements, and in every other entry point
+ *             (ptau_subgroup_check, check_input, transform_ratios) the exact test runs — never anything weaker than the
+ *             reference's choice;
+ *   NO      : no membership test. */
 enum { PTAU_SUBGROUP_AUTO = 0, PTAU_SUBGROUP_DIRECT = 1, PTAU_SUBGROUP_BATCHED = 2, PTAU_SUBGROUP_NO = 3 };
 /* setup_utils::BatchExpMode — src/bin/contribute.rs:134-139.  arkworks' batch_exp returns [k]P for ANY curve point, so:
  *   DIRECT                 : plain signed-window multiplication, exact on the whole curve;
@@ -100,6 +109,9 @@ typedef struct ptau_timing {
      * proofs of knowledge / chunk-0 before-after checks.  ratio_checks == 0 after a call with ratio_check != 0 means "NOT
      * PERFORMED": a chunk without tauG2 elements and no tau_g2_check (see ptau_verify_chunk). */
     uint32_t ratio_checks, pok_checks;
+    /* verify path: latency of the bucket MSMs' tails (bucket reduction, row sums, Horner, normalisation: a few waves), which
+     * run on a second stream beside the next vector's kernels.  kernel_ms / msm_ms hold only the part that was not hidden. */
+    double msm_tail_ms;
 } ptau_timing;
 
 const char *ptau_strerror(int code);

@@ -60,6 +60,8 @@ pub struct PtauTiming {
     pub msm_ms: f64,
     pub ratio_checks: u32,
     pub pok_checks: u32,
+    /// latency of the MSM tails that ran beside the next vector's kernels (verify path)
+    pub msm_tail_ms: f64,
 }
 
 pub const PTAU_BATCH_EXP_INPUT_IN_SUBGROUP: c_int = 0x100;

@@ -51,7 +51,8 @@ class ptau_timing(ctypes.Structure):
     _fields_ = [("h2d_ms", ctypes.c_double), ("kernel_ms", ctypes.c_double), ("d2h_ms", ctypes.c_double),
                 ("scalar_mul_ms", ctypes.c_double), ("normalize_ms", ctypes.c_double), ("points", ctypes.c_uint64),
                 ("decompress_ms", ctypes.c_double), ("subgroup_ms", ctypes.c_double), ("msm_ms", ctypes.c_double),
-                ("ratio_checks", ctypes.c_uint32), ("pok_checks", ctypes.c_uint32)]
+                ("ratio_checks", ctypes.c_uint32), ("pok_checks", ctypes.c_uint32),
+                ("msm_tail_ms", ctypes.c_double)]
 
 
 def load_library():

@@ -148,9 +148,24 @@ struct DeviceCtx {
         std::atomic<size_t> *ready = nullptr;   // progress mark of the streaming new-challenge hash
         size_t mark = 0;
     } pending;
+    // verify: the TAIL of a vector's bucket MSM (bucket reduction -> row sums -> Horner -> normalisation: a few waves of
+    // serial latency, 3 ms on BLS12-377 G1, 13 ms on G2) runs on its own stream beside the NEXT vector's square roots and
+    // membership tests; its results are collected by finish_msm_tail() before the next MSM touches the workspace
+    hipStream_t tail_stream = nullptr;
+    hipEvent_t tev[4] = {};   // head start, head end (main stream), tail end (tail stream), buckets consumed (main stream)
+    void *bk_bytes = nullptr, *bk_pre = nullptr;   // membership-fused MSM: the bucket sums as uncompressed points, inversion scratch
+    size_t bk_bytes_cap = 0, bk_pre_cap = 0;
+    uint8_t *t_buf = nullptr;   // [pre 8 KB | results 4 KB | err 16 B]
+    struct PendingTail {
+        bool active = false;
+        uint8_t *out_a = nullptr, *out_b = nullptr;
+        int osz = 0;
+        uint64_t points = 0;
+    } tail;
     ptau_timing timing = {};
     double busy_ms = 0;   // kernel time since the library was loaded, every call on this device (under mu)
 };
+constexpr size_t TB_PRE = 0, TB_SMALL = 8192, TB_ERR = 12288, TB_SIZE = 16384;
 DeviceCtx g_ctx[MAX_DEVICES];
 // second context per device (own stream and small buffers) for the lone beta_g2 element of a contribution: its update is
 // ONE thread's scalar multiplication (8 ms on BLS12-377, ~130 ms on MNT6 G2) and runs beside the four vectors.  Only used
@@ -173,15 +188,15 @@ int ensure_ctx(int device, DeviceCtx *&c, const Err &err, bool side = false) {
     HIP_TRY(hipSetDevice(device));
     std::lock_guard<std::mutex> init_lk(g_init_mu);
     if (c->ready) return PTAU_OK;
-    hipStream_t st[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t evs[8] = {};
-    void *bufs[4] = {nullptr, nullptr, nullptr, nullptr};
-    const size_t buf_sz[4] = {sizeof(uint32_t) * (1 + ptau::SCALAR_TABLE_ENTRIES) * 24, 256, 4096, 16384};
+    hipStream_t st[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t evs[12] = {};
+    void *bufs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    const size_t buf_sz[5] = {sizeof(uint32_t) * (1 + ptau::SCALAR_TABLE_ENTRIES) * 24, 256, 4096, 16384, TB_SIZE};
     hipError_t e = hipSuccess;
     const char *what = "";
-    for (int i = 0; i < 4 && e == hipSuccess; i++) { e = hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking); what = "hipStreamCreateWithFlags"; }
-    for (int i = 0; i < 8 && e == hipSuccess; i++) { e = hipEventCreate(&evs[i]); what = "hipEventCreate"; }
-    for (int i = 0; i < 4 && e == hipSuccess; i++) { e = hipMalloc(&bufs[i], buf_sz[i]); what = "hipMalloc"; }
+    for (int i = 0; i < 5 && e == hipSuccess; i++) { e = hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking); what = "hipStreamCreateWithFlags"; }
+    for (int i = 0; i < 12 && e == hipSuccess; i++) { e = hipEventCreate(&evs[i]); what = "hipEventCreate"; }
+    for (int i = 0; i < 5 && e == hipSuccess; i++) { e = hipMalloc(&bufs[i], buf_sz[i]); what = "hipMalloc"; }
     if (e != hipSuccess) {
         for (auto s : st) if (s) (void)hipStreamDestroy(s);
         for (auto v : evs) if (v) (void)hipEventDestroy(v);
@@ -192,13 +207,17 @@ int ensure_ctx(int device, DeviceCtx *&c, const Err &err, bool side = false) {
     c->side_stream = st[1];
     c->copy_stream = st[2];
     c->pair_stream = st[3];
+    c->tail_stream = st[4];
     for (int i = 0; i < 6; i++) c->ev[i] = evs[i];
     c->cev[0] = evs[6];
     c->cev[1] = evs[7];
+    for (int i = 0; i < 4; i++) c->tev[i] = evs[8 + i];
+    c->t_buf = (uint8_t *)bufs[4];
     c->d_table = (uint32_t *)bufs[0];
     c->d_err = (int *)bufs[1];
     c->d_small = bufs[2];
     c->s_buf = (uint8_t *)bufs[3];
+    c->tail = DeviceCtx::PendingTail{};
     c->ready = true;
     return PTAU_OK;
 }
@@ -221,6 +240,8 @@ int errbits_to_code(int bits, const Err &err) {
     return err.fail(PTAU_E_NOT_IN_SUBGROUP, "element is not in the prime-order subgroup");
 }
 
+int enqueue_subgroup_kernels(DeviceCtx *c, int curve, int group, const GroupOps *ops, const uint8_t *d_in, int cin, uint64_t n,
+                             const Err &err, int *d_err_override = nullptr);
 int run_subgroup_check_dev(DeviceCtx *c, int curve, int group, const GroupOps *ops, const uint8_t *d_in, int cin, uint64_t n,
                            const Err &err);
 int flush_pending_copy(DeviceCtx *c, const Err &err);
@@ -379,8 +400,21 @@ using ptau::msm_plan;
 // sum_i k_i * P_i (i < n) -> ONE serialized affine point in host memory; with out_b also the SHIFTED sum
 // sum_i k_i * P_{i+1} (power_pairs: d_in must then hold n + 1 points).  Bucket method (K4); caller holds the
 // device mutex.
+// defer_tail: everything after the last slice's bucket sums goes to the tail stream and NOTHING is waited for; out_a / out_b
+// are written by finish_msm_tail(), which the caller must reach before the next MSM on this context.
+// fuse (with defer_tail, PRF scalars and both sums): the membership-fused form — msm_plan's comment has the argument.  Every
+// bucket sum of both sums is normalised and put through the group's exact membership test (enqueue_subgroup_kernels); a failure
+// lands in the tail's error word as PTAU_E_NOT_IN_SUBGROUP.  Sum A covers points 0 .. n-1, sum B points 1 .. n.
+struct MsmFuse { int curve, group; };
 int run_msm_bucket_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, int cin, uint64_t n, ptau::ScalarSource src,
-                       uint8_t *out_a, uint8_t *out_b, int cout, const Err &err) {
+                       uint8_t *out_a, uint8_t *out_b, int cout, const Err &err, bool defer_tail = false,
+                       const MsmFuse *fuse = nullptr) {
+    if (fuse && !(defer_tail && src.mode == ptau::SCALAR_PRF && out_b)) return err.fail(PTAU_E_ARG, "membership-fused MSM: wrong call form");
+    const int test_cost = fuse ? std::max(1, ops->subgroup_cost_adds) : 0;
+    if (c->tail.active) {   // left behind by a call that failed: its results are of no interest, its kernels must be done
+        HIP_TRY(hipStreamSynchronize(c->tail_stream));
+        c->tail.active = false;
+    }
     const int isz = cin ? ops->comp : ops->uncomp, osz = cout ? ops->comp : ops->uncomp;
     const int nsum = out_b ? 2 : 1;
     const int scalar_bits = src.mode == ptau::SCALAR_PRF ? ptau::PRF_BITS : ops->fr_bits;
@@ -390,7 +424,7 @@ int run_msm_bucket_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, i
     // workspace carve-up (sized for the largest slice; W*B peaks at the largest c)
     size_t wb_max = 0, w_max = 0;
     for (uint64_t m : {cap, n % MSM_SLICE_POINTS ? n % MSM_SLICE_POINTS : cap}) {
-        const ptau::MsmPlan pl = msm_plan(std::max<uint64_t>(m, 1), scalar_bits);
+        const ptau::MsmPlan pl = msm_plan(std::max<uint64_t>(m, 1), scalar_bits, 0, test_cost);
         wb_max = std::max(wb_max, (size_t)pl.W * pl.B);
         w_max = std::max(w_max, (size_t)pl.W);
     }
@@ -413,18 +447,21 @@ int run_msm_bucket_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, i
     uint8_t *parts = w8;                              w8 += sz_parts;
     uint8_t *totals = w8;                             w8 += sz_totals;   // [sum][slice] Jacobians, then the final [sum]
     uint8_t *runs = w8;                               // run partials of the accumulate pass
-    HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
-    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    int *d_err = defer_tail ? (int *)(c->t_buf + TB_ERR) : c->d_err;
+    hipStream_t ts = c->stream;   // the stream of the tail kernels
+    HIP_TRY(hipMemsetAsync(d_err, 0, sizeof(int), c->stream));
+    HIP_TRY(hipEventRecord(defer_tail ? c->tev[0] : c->ev[0], c->stream));
     uint64_t li = 0;
     for (uint64_t off = 0; off < n || (n == 0 && li == 0); off += MSM_SLICE_POINTS, li++) {
         const uint64_t m = std::min(MSM_SLICE_POINTS, n - off);
-        const ptau::MsmPlan pl = msm_plan(std::max<uint64_t>(m, 1), scalar_bits);
+        const ptau::MsmPlanEx pl = msm_plan(std::max<uint64_t>(m, 1), scalar_bits, 0, test_cost);
         const uint64_t wb = (uint64_t)pl.W * pl.B;
         ptau::ScalarSource s2 = src;
+        if (fuse) s2.prf_bits = pl.bits;
         if (s2.mode == ptau::SCALAR_ARRAY) s2.ptr += off * ops->fr_limbs32;
         s2.index_base += off;
         HIP_TRY(hipMemsetAsync(counts, 0, wb * 4, c->stream));
-        ops->msm_prepare(c->stream, d_in + off * isz, cin, aff, dig, counts, m + (nsum - 1), m, s2, pl, c->d_err);
+        ops->msm_prepare(c->stream, d_in + off * isz, cin, aff, dig, counts, m + (nsum - 1), m, s2, pl, d_err);
         hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, c->stream, counts, offsets, run_offsets, (uint32_t)wb);
         if (m) hipLaunchKernelGGL(ptau::msm_scatter_kernel<0>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, dig, counts, sorted, m, pl);
         const uint64_t max_runs = wb + (uint64_t)pl.W * m / ptau::MSM_RUN + 1;
@@ -432,22 +469,48 @@ int run_msm_bucket_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, i
             ops->msm_accumulate(c->stream, aff, sorted, offsets, run_offsets, runs, (uint32_t)sidx, (uint32_t)wb, max_runs);
             ops->msm_combine(c->stream, runs, run_offsets, buckets + (size_t)sidx * wb * ops->jac_bytes, wb);
         }
+        const bool last_slice = off + MSM_SLICE_POINTS >= n;
+        if (fuse) {   // the bucket sums as points, before the reduction below reuses their memory
+            const uint64_t nb = (uint64_t)nsum * wb;
+            if ((rc = grow(c->bk_bytes, c->bk_bytes_cap, nb * ops->uncomp, err))) return rc;
+            if ((rc = grow(c->bk_pre, c->bk_pre_cap, nb * ops->fe_bytes, err))) return rc;
+            ops->normalize(c->stream, buckets, c->bk_pre, (uint8_t *)c->bk_bytes, 0, nb, (nb + 3) / 4, 0, d_err);
+        }
+        if (defer_tail && last_slice) {   // last slice: the main stream is done with the buckets here
+            HIP_TRY(hipEventRecord(c->tev[3], c->stream));
+            HIP_TRY(hipStreamWaitEvent(c->tail_stream, c->tev[3], 0));
+            ts = c->tail_stream;
+        }
+        if (fuse && (rc = enqueue_subgroup_kernels(c, fuse->curve, fuse->group, ops, (const uint8_t *)c->bk_bytes, 0, (uint64_t)nsum * wb, err, d_err)))
+            return rc;
+        if (defer_tail && last_slice) HIP_TRY(hipEventRecord(c->tev[1], c->stream));
         // rows = nsum * W windows from here on
         const uint32_t rows = (uint32_t)(nsum * pl.W);
         uint32_t cols = pl.B / pl.seg;
-        ops->msm_bucket_reduce(c->stream, buckets, parts, pl, (uint64_t)rows * cols);
+        ops->msm_bucket_reduce(ts, buckets, parts, pl, (uint64_t)rows * cols);
         uint8_t *cur = parts, *nxt = buckets;   // ping-pong: the buckets are dead once reduced
         while (cols > 1) {
             const uint32_t T = (cols + 15) / 16;
-            ops->reduce_rows(c->stream, cur, nxt, rows, cols, T);
+            ops->reduce_rows(ts, cur, nxt, rows, cols, T);
             std::swap(cur, nxt);
             cols = T;
         }
-        ops->msm_horner(c->stream, cur, totals + (size_t)li * ops->jac_bytes, pl, nsum, nslice);   // sum s -> totals[s * nslice + li]
+        ops->msm_horner(ts, cur, totals + (size_t)li * ops->jac_bytes, pl, nsum, nslice);   // sum s -> totals[s * nslice + li]
     }
     uint8_t *fin = totals + (size_t)nsum * nslice * ops->jac_bytes;
     for (int sidx = 0; sidx < nsum; sidx++)
-        ops->reduce_sum(c->stream, totals + (size_t)sidx * nslice * ops->jac_bytes, fin + (size_t)sidx * ops->jac_bytes, li, 1);
+        ops->reduce_sum(ts, totals + (size_t)sidx * nslice * ops->jac_bytes, fin + (size_t)sidx * ops->jac_bytes, li, 1);
+    if (defer_tail) {
+        ops->normalize(ts, fin, c->t_buf + TB_PRE, c->t_buf + TB_SMALL, cout, nsum, nsum, 0, d_err);
+        HIP_TRY(hipEventRecord(c->tev[2], ts));
+        HIP_TRY(hipGetLastError());
+        c->tail.active = true;
+        c->tail.out_a = out_a;
+        c->tail.out_b = out_b;
+        c->tail.osz = osz;
+        c->tail.points = n * nsum;
+        return PTAU_OK;
+    }
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     ops->normalize(c->stream, fin, c->pre, (uint8_t *)c->d_small, cout, nsum, nsum, 0, c->d_err);
     int bits = 0;
@@ -521,9 +584,55 @@ int run_msm_naive_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, in
 }
 
 
+// Collect a deferred MSM tail: wait for it (it has usually finished long ago), copy the one or two result points out and
+// book the time.  kernel_ms gets the head (main stream) plus only what of the tail was NOT hidden: the part that ran past
+// `main_end` (the end of the next vector's kernels on the main stream), or all of it when nothing followed (main_end null).
+int finish_msm_tail(DeviceCtx *c, const Err &err, hipEvent_t *main_end) {
+    if (!c->tail.active) return PTAU_OK;
+    c->tail.active = false;
+    HIP_TRY(hipStreamSynchronize(c->tail_stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));   // the bucket membership kernels of the fused form write the same error word
+    HIP_TRY(hipGetLastError());
+    int bits = 0;
+    HIP_TRY(hipMemcpy(&bits, c->t_buf + TB_ERR, sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(c->tail.out_a, c->t_buf + TB_SMALL, c->tail.osz, hipMemcpyDeviceToHost));
+    if (c->tail.out_b) HIP_TRY(hipMemcpy(c->tail.out_b, c->t_buf + TB_SMALL + c->tail.osz, c->tail.osz, hipMemcpyDeviceToHost));
+    float head = 0, lat = 0, past = 0;
+    HIP_TRY(hipEventElapsedTime(&head, c->tev[0], c->tev[1]));
+    HIP_TRY(hipEventElapsedTime(&lat, c->tev[3], c->tev[2]));
+    // what of the tail ran past the main stream's own work: past the next vector's kernels, or past this MSM's head
+    if (hipEventElapsedTime(&past, main_end ? *main_end : c->tev[1], c->tev[2]) != hipSuccess) { (void)hipGetLastError(); past = lat; }
+    past = std::min(std::max(past, 0.0f), lat);
+    c->timing.kernel_ms += head + past;
+    c->busy_ms += head + past;
+    c->timing.msm_ms += head + past;
+    c->timing.msm_tail_ms += lat;
+    c->timing.points += c->tail.points;
+    return errbits_to_code(bits, err);
+}
+
+// PTAU_BATCHED_SUBGROUP=0: Auto / Batched run the exact per-element membership test everywhere (A/B runs).
+constexpr uint64_t BATCHED_SUBGROUP_MIN = 1ull << 12;
+bool use_batched_subgroup() {
+    static const bool v = [] {
+        const char *e = getenv("PTAU_BATCHED_SUBGROUP");
+        return !(e && strcmp(e, "0") == 0);
+    }();
+    return v;
+}
+
+// PTAU_MSM_TAIL_OVERLAP=0: the verify path waits for every MSM as a whole (A/B runs).
+bool use_msm_tail_overlap() {
+    static const bool v = [] {
+        const char *e = getenv("PTAU_MSM_TAIL_OVERLAP");
+        return !(e && strcmp(e, "0") == 0);
+    }();
+    return v;
+}
+
 int run_msm_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, int cin, uint64_t n, ptau::ScalarSource src,
-                uint8_t *out_a, uint8_t *out_b, int cout, const Err &err) {
-    if (use_bucket_msm()) return run_msm_bucket_dev(c, ops, d_in, cin, n, src, out_a, out_b, cout, err);
+                uint8_t *out_a, uint8_t *out_b, int cout, const Err &err, bool defer_tail = false, const MsmFuse *fuse = nullptr) {
+    if (use_bucket_msm() || fuse) return run_msm_bucket_dev(c, ops, d_in, cin, n, src, out_a, out_b, cout, err, fuse || (defer_tail && use_msm_tail_overlap()), fuse);
     const int isz = cin ? ops->comp : ops->uncomp;
     int rc = run_msm_naive_dev(c, ops, d_in, cin, n, src, out_a, cout, err);
     if (rc || !out_b) return rc;
@@ -548,7 +657,8 @@ bool cofactor_is_one(int curve, int group) {
 // Cofactor-1 groups (MNT G1) need only the on-curve test.  Caller holds the device mutex.
 // Enqueue only (no error-word reset, no synchronisation): events ev[0] / ev[1] bracket the membership kernels.
 int enqueue_subgroup_kernels(DeviceCtx *c, int curve, int group, const GroupOps *ops, const uint8_t *d_in, int cin, uint64_t n,
-                             const Err &err) {
+                             const Err &err, int *d_err_override) {
+    int *const d_err = d_err_override ? d_err_override : c->d_err;
     const int isz = cin ? ops->comp : ops->uncomp;
     const uint64_t launch_cap =
         std::max<uint64_t>(256, std::min(MAX_LAUNCH_POINTS, MAX_WINDOW_TABLE_BYTES / (ptau::WINDOW_ENTRIES * ops->wtab_entry_bytes)));
@@ -557,9 +667,9 @@ int enqueue_subgroup_kernels(DeviceCtx *c, int curve, int group, const GroupOps 
                            hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     if (ops->endo_subgroup && use_endo_subgroup()) {
-        ops->endo_subgroup(c->stream, d_in, cin, n, c->d_err);   // on-curve test included
+        ops->endo_subgroup(c->stream, d_in, cin, n, d_err);   // on-curve test included
     } else if (!cin) {
-        ops->on_curve(c->stream, d_in, n, c->d_err);
+        ops->on_curve(c->stream, d_in, n, d_err);
     }
     if (!(ops->endo_subgroup && use_endo_subgroup()) && !cofactor_is_one(curve, group)) {
         for (uint64_t off = 0; off < n; off += launch_cap) {
@@ -569,12 +679,12 @@ int enqueue_subgroup_kernels(DeviceCtx *c, int curve, int group, const GroupOps 
             if ((rc = grow(c->wtab, c->wtab_cap, m * ptau::WINDOW_ENTRIES * ops->wtab_entry_bytes, err))) return rc;
             if (ops->subgroup_via_glv && use_endo_subgroup())   // [a]P + [b]phi(P) == O, |a|, |b| ~ sqrt(r): half the doublings, exact
                 ops->window_scalar_mul(c->stream, d_in + off * isz, cin, c->scratch, c->wtab, m,
-                                       ptau::ScalarSource{ptau::SCALAR_SUBGROUP_ENDO, nullptr, 0, 0, 0}, 0, /*use_glv=*/1, c->d_err);
+                                       ptau::ScalarSource{ptau::SCALAR_SUBGROUP_ENDO, nullptr, 0, 0, 0}, 0, /*use_glv=*/1, d_err);
             else
                 ops->window_scalar_mul(c->stream, d_in + off * isz, cin, c->scratch, c->wtab, m,
-                                       ptau::ScalarSource{ptau::SCALAR_FIXED, c->d_table, 0, 0, 0}, 0, /*use_glv=*/0, c->d_err);
-            if (via_psi) ops->psi_check(c->stream, d_in + off * isz, cin, c->scratch, m, c->d_err);
-            else ops->expect_infinity(c->stream, c->scratch, m, c->d_err);
+                                       ptau::ScalarSource{ptau::SCALAR_FIXED, c->d_table, 0, 0, 0}, 0, /*use_glv=*/0, d_err);
+            if (via_psi) ops->psi_check(c->stream, d_in + off * isz, cin, c->scratch, m, d_err);
+            else ops->expect_infinity(c->stream, c->scratch, m, d_err);
         }
     }
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
@@ -636,8 +746,15 @@ int run_verify_vector(DeviceCtx *c, int curve, int group, const GroupOps *ops, c
     const int nonzero = (check_output == PTAU_CHECK_ONLY_NON_ZERO || check_output == PTAU_CHECK_FULL) ? 1 : 0;
     ops->decompress(c->stream, (const uint8_t *)c->d_in, (uint8_t *)d_out, n, nonzero, c->d_err);
     HIP_TRY(hipEventRecord(c->ev[5], c->stream));
-    const bool want_subgroup = subgroup_check_mode != PTAU_SUBGROUP_NO || check_output == PTAU_CHECK_ONLY_IN_GROUP ||
-                               check_output == PTAU_CHECK_FULL;
+    bool want_subgroup = subgroup_check_mode != PTAU_SUBGROUP_NO || check_output == PTAU_CHECK_ONLY_IN_GROUP ||
+                         check_output == PTAU_CHECK_FULL;
+    // SubgroupCheckMode::Batched, and Auto on more than 2^12 elements (setup-utils check_subgroup: BATCH_SIZE = 1 << 12,
+    // SECURITY_PARAM = 128): the batched membership test, here through the buckets of the ratio check's MSM (msm_plan); it
+    // needs that MSM, so without a ratio check — and for Direct, and for short vectors — the exact per-element test runs
+    const bool fused = want_subgroup && ratio_seed && n > BATCHED_SUBGROUP_MIN && use_batched_subgroup() &&
+                       (subgroup_check_mode == PTAU_SUBGROUP_AUTO || subgroup_check_mode == PTAU_SUBGROUP_BATCHED) &&
+                       !cofactor_is_one(curve, group);
+    if (fused) want_subgroup = false;
     // the membership kernels are queued behind the decompression at once (one error word collects both), so that the
     // previous vector's deferred copy below has real work to hide behind
     if (want_subgroup && (rc = enqueue_subgroup_kernels(c, curve, group, ops, (const uint8_t *)d_out, 0, n, err))) return rc;
@@ -659,10 +776,13 @@ int run_verify_vector(DeviceCtx *c, int curve, int group, const GroupOps *ops, c
         c->timing.subgroup_ms += ms;
     }
     c->timing.points += n;
+    // the previous vector's MSM tail ran beside the kernels just waited for
+    if ((rc = finish_msm_tail(c, err, want_subgroup ? &c->ev[1] : &c->ev[5]))) return rc;
     if ((rc = errbits_to_code(bits, err))) return rc;
-    if (ratio_seed && n >= 2) {   // power_pairs on the vector while it is still resident in HBM
+    if (ratio_seed && n >= 2) {   // power_pairs on the vector while it is still resident in HBM; its tail is collected later
         const ptau::ScalarSource src{ptau::SCALAR_PRF, nullptr, ratio_seed[0], ratio_seed[1], index_base};
-        if ((rc = run_msm_dev(c, ops, (const uint8_t *)d_out, 0, n - 1, src, pair_a, pair_b, 0, err))) return rc;
+        const MsmFuse fz{curve, group};
+        if ((rc = run_msm_dev(c, ops, (const uint8_t *)d_out, 0, n - 1, src, pair_a, pair_b, 0, err, /*defer_tail=*/true, fused ? &fz : nullptr))) return rc;
     }
     c->pending.src = d_out;
     c->pending.dst = out;
@@ -1405,7 +1525,7 @@ int verify_chunk_impl(const ptau_params *p, const uint8_t *challenge, size_t cha
         pi += v.n * v.ops->comp;
         po += v.n * v.ops->uncomp;
     }
-    if ((rc = flush_pending_copy(c, err))) {   // the last vector's copy
+    if ((rc = flush_pending_copy(c, err)) || (rc = finish_msm_tail(c, err, nullptr))) {   // the last vector's copy and MSM tail
         hipStreamSynchronize(c->side_stream);
         return rc;
     }

@@ -203,15 +203,17 @@ struct ScalarSource {
     const uint32_t *ptr;      // TAU_TABLE: the tau^(2^k) table; FIXED: NL canonical limbs; ARRAY: n x NL canonical limbs
     uint64_t seed0, seed1;    // PRF: 128-bit seed
     uint64_t index_base;      // PRF: global index of element 0 (slices of one vector agree across GPUs)
+    int prf_bits = 0;         // PRF: width of rho in bits (0 = PRF_BITS; up to 255 for the membership-fused MSM, see msm_plan)
 };
 
 // The random coefficient rho_idx of merge_pairs / power_pairs.  setup-utils draws Fr::rand from thread_rng — rand 0.8's
 // ChaCha12 generator; here the SAME cipher as a counter-mode PRF, so that any slice of a vector, on any GPU, sees the same
 // rho for the same global index: one ChaCha12 block per element, key = the per-verification 128-bit secret (from the OS)
-// followed by a fixed domain tag, block counter = the element's global index; rho = words 0..3 of the block with the top bit
-// cleared (PRF_BITS = 127).  ~600 plain ALU operations per element, against the ~1400 of converting the point.
+// followed by a fixed domain tag, block counter = the element's global index; rho = the low `bits` bits of words 0..7 of the
+// block (PRF_BITS = 127: words 0..3 with the top bit cleared).  ~600 plain ALU operations per element, against the ~1400 of
+// converting the point.
 PTAU_HD uint32_t prf_rotl(uint32_t v, int n) { return (v << n) | (v >> (32 - n)); }
-PTAU_HD void prf_rho(uint64_t seed0, uint64_t seed1, uint64_t idx, uint32_t (&out)[4]) {
+PTAU_HD void prf_rho(uint64_t seed0, uint64_t seed1, uint64_t idx, int bits, uint32_t (&out)[8]) {
     const uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u,
                             (uint32_t)seed0, (uint32_t)(seed0 >> 32), (uint32_t)seed1, (uint32_t)(seed1 >> 32),
                             0x75617470u /* "ptau" */, 0x6f68722du /* "-rho" */, 0x72657020u, 0x78646e69u,
@@ -231,14 +233,20 @@ PTAU_HD void prf_rho(uint64_t seed0, uint64_t seed1, uint64_t idx, uint32_t (&ou
     }
 #undef PTAU_QR
 #pragma unroll
-    for (int i = 0; i < 4; i++) out[i] = x[i] + s[i];
-    out[3] &= 0x7fffffffu;
+    for (int i = 0; i < 8; i++) {
+        const int lo = 32 * i;
+        const uint32_t m = bits >= lo + 32 ? 0xffffffffu : (bits <= lo ? 0u : ((1u << (bits - lo)) - 1u));
+        out[i] = (x[i] + s[i]) & m;
+    }
 }
 
 // Number of random bits in a power_pairs coefficient.  setup-utils draws full-width Fr::rand; the check
 // sum_i rho_i (v_{i+1} - tau v_i) == O is equally sound with 127-bit rho (a cheating vector passes with
 // probability 2^-127: distinct 127-bit values stay distinct mod r > 2^252), and the MSM is half as long.
 constexpr int PRF_BITS = 127;   // + the sign-recoding carry = 128 = 8 full windows of 16 bits at 2^20 points
+// Widest rho the membership-fused MSM asks for (msm_plan with bucket_test_cost > 0 at >= 4096 points: c >= 5, W c - 1 <= 164);
+// every scalar field here has more than 252 bits, so the values stay distinct and canonical.
+constexpr int PRF_MAX_BITS = 200;
 
 // The scalar of element i under a ScalarSource, as NL canonical 32-bit limbs.
 template <class Fr>
@@ -251,11 +259,11 @@ PTAU_HD void thread_scalar(const ScalarSource &src, uint64_t i, uint32_t (&k)[Fr
 #pragma unroll
         for (int j = 0; j < NL; j++) k[j] = src.ptr[i * NL + j];
     } else if (src.mode == SCALAR_PRF) {     // random linear combination coefficients
-        static_assert(NL * 32 >= PRF_BITS && Fr::Params::BITS > PRF_BITS, "scalar field too small for the PRF width");
-        uint32_t rho[4];
-        prf_rho(src.seed0, src.seed1, src.index_base + i, rho);
+        static_assert(NL >= 8 && Fr::Params::BITS > PRF_MAX_BITS, "scalar field too small for the PRF width");
+        uint32_t rho[8];
+        prf_rho(src.seed0, src.seed1, src.index_base + i, src.prf_bits ? src.prf_bits : PRF_BITS, rho);
 #pragma unroll
-        for (int j = 0; j < NL; j++) k[j] = j < 4 ? rho[j] : 0u;
+        for (int j = 0; j < NL; j++) k[j] = j < 8 ? rho[j] : 0u;
     } else {
         Fr ek = scalar_for_index<Fr>(src.ptr, i);
         ek.to_canonical(k);
@@ -938,21 +946,40 @@ struct MsmPlan {
 // c - 2 scalar bits is rejected when another one exists (its few buckets would each collect m / 2^t points: the run
 // splitting keeps that parallel, but the combine pass then walks long run lists).  127-bit power_pairs coefficients
 // at 2^20 points give c = 16: 8 full windows, 32 points per bucket.
-inline MsmPlan msm_plan(uint64_t m, int scalar_bits, int force_c = 0) {
-    MsmPlan best{};
+// bucket_test_cost > 0 selects the plan of the MEMBERSHIP-FUSED MSM of the verify path (capi.hip, run_verify_vector): every
+// bucket sum of every window is tested for prime-order-subgroup membership, which makes each window one round of the batched
+// subgroup check of setup-utils (SubgroupCheckMode::Batched, SECURITY_PARAM = 128): a point outside the subgroup lands, in
+// each window independently, in a uniformly random bucket (or in none, digit 0) and that window's test passes only if its image
+// in the cofactor group is cancelled by what the other points left in exactly that bucket: probability <= 2^-(c-1) per
+// window.  The plan therefore takes W = ceil(128 / (c - 1)) FULL windows — scalars of W c - 1 random bits (`bits`), which is
+// also a valid (longer) coefficient of the random linear combination — and weighs a bucket with the cost of its test
+// (bucket_test_cost, in mixed additions).
+struct MsmPlanEx : MsmPlan { int bits; };
+inline MsmPlanEx msm_plan(uint64_t m, int scalar_bits, int force_c = 0, int bucket_test_cost = 0) {
+    MsmPlanEx best{};
     double best_cost = -1;
     bool best_balanced = false;
     for (int c = 2; c <= 16; c++) {
         if (force_c && c != force_c) continue;
-        const int W = (scalar_bits + 1 + c - 1) / c;
-        const int top_bits = scalar_bits + 1 - (W - 1) * c;
-        const bool balanced = top_bits >= c - 2;
-        const double cost = (double)W * ((double)m + 3.0 * (double)(1u << (c - 1)));
+        int W = (scalar_bits + 1 + c - 1) / c, bits = scalar_bits;
+        bool balanced;
+        if (bucket_test_cost > 0) {
+            if (c < 3) continue;
+            W = (128 + c - 2) / (c - 1);
+            bits = W * c - 1;
+            if (bits > PRF_MAX_BITS) continue;
+            balanced = true;
+        } else {
+            const int top_bits = scalar_bits + 1 - (W - 1) * c;
+            balanced = top_bits >= c - 2;
+        }
+        const double cost = (double)W * ((double)m + (3.0 + bucket_test_cost) * (double)(1u << (c - 1)));
         if (best_cost < 0 || (balanced && !best_balanced) || (balanced == best_balanced && cost < best_cost)) {
             best.c = c;
             best.W = W;
             best.B = 1u << (c - 1);
             best.seg = best.B < 8 ? best.B : 8;
+            best.bits = bits;
             best_cost = cost;
             best_balanced = balanced;
         }
@@ -1633,6 +1660,9 @@ struct GroupOps {
     void (*psi_check)(hipStream_t, const uint8_t *in, int cin, const void *scratch, uint64_t n, int *err);
     void (*decompress)(hipStream_t, const uint8_t *in, uint8_t *out, uint64_t n, int check_nonzero, int *err);
     const uint32_t *group_order;   // r, canonical 32-bit limbs (fr_limbs32)
+    // rough cost of ONE exact membership test in mixed additions of the group (msm_plan's bucket weight in the membership-fused
+    // MSM): doublings x 7/11 + additions of the test the library runs for this group
+    int subgroup_cost_adds;
     // O(1) host-side decompression for the pairing tail (a handful of public-key / head elements)
     int (*decompress_host)(const uint8_t *in, uint8_t *out, uint64_t n, int check_nonzero);
 };
@@ -1854,6 +1884,15 @@ struct Launch {
         }
         o.decompress = decompress;
         o.group_order = Fr::Params::MOD;
+        {
+            using Cfg = typename G::J::CfgT;
+            constexpr int RB = Fr::Params::BITS;
+            o.subgroup_cost_adds = Cfg::ENDO_KIND == 1 ? 93          // two chains of 63 doublings + 6 additions
+                                 : Cfg::ENDO_KIND == 2 ? 46          // one chain
+                                 : Cfg::GLV_KIND == 2 ? RB / 2 * 7 / 11 + RB / 8     // [a]P + [b]phi(P), halves of r
+                                 : Cfg::PSI_KIND == 1 ? RB / 2 * 8 / 14 + RB / 8     // [|t - 1|]P, a != 0 doublings
+                                 : RB * 8 / 12 + RB / 4;                              // [r]P (cofactor-1 groups never get here)
+        }
         o.decompress_host = decompress_host;
         return o;
     }

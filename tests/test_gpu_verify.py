@@ -533,3 +533,64 @@ def test_small_order_points_through_the_window_loops(name, group, pkg, cref):
         for mode in (pkg.BatchExpMode.Auto, pkg.BatchExpMode.Direct):
             got = pkg.phase1_cli.apply_powers(name, group, data, n, start, tau, coeff, False, False, batch_exp_mode=mode)
             assert got == exp, (name, group, start, tau, coeff, mode)
+
+
+@pytest.mark.parametrize("name", ["bls12_377", "bw6", "mnt4_753"])
+def test_batched_subgroup_check_through_the_msm_buckets(name, pkg):
+    """SubgroupCheckMode::Auto on more than 2^12 elements (and ::Batched) with the ratio check on: the membership test runs on
+    the bucket sums of the ratio check's own MSM (capi.hip run_verify_vector, msm_plan) — setup-utils' batched check with
+    SECURITY_PARAM = 128.  An honest 2^13 chunk passes and reports no per-element membership time; one element outside the
+    subgroup — first, middle, last of a vector, in G1 and G2, a cofactor-only point, and a cancelling pair P, -P — is
+    rejected with the same code as the exact test (Direct), which is also run on the same bytes."""
+    c = CURVES[name]
+    rng = random.Random(31)
+    lg = 13
+    n = 1 << lg
+    prm = pkg.Phase1Parameters.new_chunk(name, 0, 0, n, 0, lg, n)
+    p = P.Params(c, P.CHUNKED, 0, n, lg, n)
+    ch0 = initial_challenge(pkg, name, prm)
+    key = pkg.PrivateKey(rng.randrange(1, c.r), rng.randrange(1, c.r), rng.randrange(1, c.r), bytes(prm.public_key_size))
+    resp = bytearray(pkg.phase1_cli.computation(ch0, prm, key))
+    resp[:64] = pkg.calculate_hash(ch0)
+    Mode = pkg.SubgroupCheckMode
+    for mode in (Mode.Auto, Mode.Batched, Mode.Direct):
+        nc = pkg.phase1_cli.verification_and_decompress(ch0, bytes(resp), prm, subgroup_check_mode=mode, ratio_check=True)
+        assert nc[:64] == pkg.calculate_hash(bytes(resp))
+        tm = pkg.phase1_cli.last_timing(0)
+        assert tm["ratio_checks"] == 4
+        if mode == Mode.Direct or name.startswith("mnt"):
+            assert tm["subgroup_ms"] > 0          # MNT G1 has cofactor 1: its (on-curve) test stays per element
+        if mode != Mode.Direct and not name.startswith("mnt"):
+            assert tm["subgroup_ms"] == 0.0       # every vector went through the buckets
+    offs = {nm: (g, o, cnt) for (nm, g, o, cnt) in p.layout(True)[0]}
+    cases = []
+    groups = (2,) if name.startswith("mnt") else (1, 2)
+    for grp in groups:
+        G = Group(c, grp)
+        bad = _off_subgroup_point(G, rng)
+        vecs = ["tau_g2"] if grp == 2 else ["tau_g1", "alpha_g1", "beta_g1"]
+        for v in vecs:
+            _, o, cnt = offs[v]
+            for pos in (0, cnt // 2 + 3, cnt - 1):
+                cases.append((G, o, [(pos, bad)]))
+        _, o, cnt = offs[vecs[0]]
+        cof = G.mul(bad, c.r)                       # a point of the cofactor subgroup alone
+        if cof is not None:
+            cases.append((G, o, [(17, cof)]))
+        cases.append((G, o, [(100, bad), (4000, G.neg(bad))]))            # P and -P: cancel only if they share a bucket in every window
+        cases.append((G, o, [(cnt - 2, bad), (cnt - 1, G.neg(bad))]))
+    for G, o, subs in cases:
+        r2 = bytearray(resp)
+        for pos, pt in subs:
+            r2[o + pos * G.comp_size:o + (pos + 1) * G.comp_size] = serde.write_point(G, pt, True)
+        for mode in (Mode.Auto, Mode.Batched, Mode.Direct):
+            with pytest.raises(pkg.PtauError) as e:
+                pkg.phase1_cli.verification_and_decompress(ch0, bytes(r2), prm, subgroup_check_mode=mode, ratio_check=True)
+            assert e.value.code == -5, (G.group, subs[0][0], mode, e.value)
+        # without the ratio check there is no MSM to ride on: the exact test runs, same verdict
+        with pytest.raises(pkg.PtauError) as e:
+            pkg.phase1_cli.verification_and_decompress(ch0, bytes(r2), prm, ratio_check=False)
+        assert e.value.code == -5
+    # the library keeps working after the rejected calls (a tail left pending by a failed call is discarded)
+    nc = pkg.phase1_cli.verification_and_decompress(ch0, bytes(resp), prm, ratio_check=True)
+    assert nc[:64] == pkg.calculate_hash(bytes(resp))

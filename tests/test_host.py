@@ -450,7 +450,7 @@ def test_file_level_tail_argument_checks_without_gpu(pkg, tmp_path):
         pkg.phase1_cli.transform_ratios_devices(buf[:-1], 0, full, [0])
     assert e.value.code == -2
     t = pkg._lib.ptau_timing()
-    assert ctypes.sizeof(t) == 9 * 8 + 8 and hasattr(t, "ratio_checks") and hasattr(t, "pok_checks")
+    assert ctypes.sizeof(t) == 9 * 8 + 8 + 8 and hasattr(t, "ratio_checks") and hasattr(t, "pok_checks") and hasattr(t, "msm_tail_ms")
 
 
 def test_host_hashing_of_several_lanes_runs_concurrently(pkg):
