@@ -231,7 +231,9 @@ def whole_chunk_extras(pkg, curve, power, log2n, dev):
                                           False, prm, device=dev)
         dt2 = time.perf_counter() - t0
         out["verify_chunk_skip_ratio_check"] = {"seconds": dt2, "chunks_verified_per_s": 1.0 / dt2}
-        modes = [("contribute_chunk_exact", pkg.BatchExpMode.Auto, "Auto, CheckForCorrectness::No (exact on any curve point: plain windows)")]
+        modes = [("contribute_chunk_exact", pkg.BatchExpMode.Auto, "Auto, CheckForCorrectness::No — the operator's default flags, exact on any curve "
+                  "point: batched membership probe of each vector, endomorphism kernels where it passes (it does: verified challenge)"),
+                 ("contribute_chunk_direct", pkg.BatchExpMode.Direct, "Direct: plain signed windows, no probe")]
         modes.insert(0, ("contribute_chunk", verified, "Auto | INPUT_IN_SUBGROUP (challenge produced by the verification above: endomorphism path"
                                                        + (" — on the MNT curves that is GLS on the G2 vector; G1 has no endomorphism)" if curve.startswith("mnt") else ")")))
         for tag, mode, what in modes:
@@ -244,7 +246,7 @@ def whole_chunk_extras(pkg, curve, power, log2n, dev):
             out[tag] = {"seconds": dt3, "chunks_per_s": 1.0 / dt3, "g1_equiv_updates_per_s": elems / dt3, "batch_exp_mode": what,
                         "includes": "phase1_cli::contribute on files from a seed: key generation, BLAKE2b(challenge) overlapped, 5 vectors "
                                     "updated (PCIe both ways), public key + BLAKE2b(response) + msync",
-                        "device_ms": tm["kernel_ms"], "h2d_ms": tm["h2d_ms"], "d2h_ms": tm["d2h_ms"]}
+                        "device_ms": tm["kernel_ms"], "membership_probe_ms": tm["subgroup_ms"], "h2d_ms": tm["h2d_ms"], "d2h_ms": tm["d2h_ms"]}
         assert open(f("c1"), "rb").read(64) == open(f("v.r.hash"), "rb").read()   # new challenge extends the response it verified
         if curve != "bls12_377":
             return out
@@ -486,9 +488,10 @@ def main():
     ap.add_argument("--log2-points", type=int, default=None, help="override the vector length of the config")
     ap.add_argument("--cpu-sample", type=int, default=None, help="points the CPU oracle updates (parity check + cpu_baseline)")
     ap.add_argument("--no-extras", action="store_true", help="skip the whole-chunk contribute / verify measurements")
-    ap.add_argument("--exact-only", action="store_true",
-                    help="launch the exact path only (no endomorphism-path lines): under rocprofv3 every launch of the kernel is then "
-                         "the one `value` and `roofline` describe, so the profile's per-kernel averages are comparable to them")
+    ap.add_argument("--exact-only", "--value-path-only", dest="exact_only", action="store_true",
+                    help="launch the path of `value` only (BatchExpMode::Auto; no Direct / asserted-membership lines): under rocprofv3 "
+                         "every launch of the kernel is then the one `value` and `roofline` describe, so the profile's per-kernel "
+                         "averages are comparable to them")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` with no launcher around it: start the N ranks here, before torch or HIP are touched
@@ -527,6 +530,7 @@ def main():
     dev = local_rank
     eb = ctypes.create_string_buffer(256)
     ENDO = int(pkg.BatchExpMode.Auto) | pkg.phase1_cli.INPUT_IN_SUBGROUP
+    DIRECT = int(pkg.BatchExpMode.Direct)
 
     def barrier():
         torch.cuda.synchronize()
@@ -560,7 +564,7 @@ def main():
                                          n, start, pkg._lib.limbs(tau, nl), None, 0, mode, dev, eb, len(eb))
             if rc:
                 raise RuntimeError("ptau_apply_powers_dev rc=%d: %s" % (rc, eb.value.decode()))
-        run(d_gen, 0, d_chal, 0, s, 0 if args.exact_only else ENDO)   # the challenge vector itself: s^i * generator
+        run(d_gen, 0, d_chal, 0, s, 0)   # the challenge vector itself: s^i * generator
         del d_gen
         return d_chal, d_resp, run, usz, csz
 
@@ -577,12 +581,13 @@ def main():
     barrier()
     busy0 = L.ptau_device_busy_ms(dev)
     t0 = time.perf_counter()
-    smul_ms = norm_ms = 0.0
+    smul_ms = norm_ms = probe_ms = 0.0
     for _ in range(args.steps):
         run(d_chal, 0, d_resp, 1, tau)
         tm = pkg.phase1_cli.last_timing(dev)      # HIP events on the library's own stream
         smul_ms += tm["scalar_mul_ms"]
         norm_ms += tm["normalize_ms"]
+        probe_ms += tm["subgroup_ms"]
     barrier()
     dt = time.perf_counter() - t0
     # kernel time of THIS rank's device over the timed region (ptau_device_busy_ms): one entry per rank in the line
@@ -591,20 +596,23 @@ def main():
         allb = [None] * world
         dist.all_gather_object(allb, busy[0])
         busy = allb
-    # the same step on the endomorphism path (membership asserted by the caller — what an operator that trusts its
-    # coordinator's verifier runs): reported next to `value`, never as `value`
-    endo = None
-    if not curve.startswith("mnt") and not args.exact_only:
-        run(d_chal, 0, d_resp, 1, tau, ENDO)
-        endo_ms = 0.0
+    # the same step with the membership ASSERTED by the caller (what an operator that trusts its coordinator's verifier runs: no
+    # probe) and on the plain path (BatchExpMode::Direct): reported next to `value`, never as `value`
+    def side_line(mode):
+        run(d_chal, 0, d_resp, 1, tau, mode)
+        k_ms = 0.0
         te = time.perf_counter()
         for _ in range(args.steps):
-            run(d_chal, 0, d_resp, 1, tau, ENDO)
-            endo_ms += pkg.phase1_cli.last_timing(dev)["scalar_mul_ms"]
+            run(d_chal, 0, d_resp, 1, tau, mode)
+            k_ms += pkg.phase1_cli.last_timing(dev)["scalar_mul_ms"]
         torch.cuda.synchronize()
-        dte = time.perf_counter() - te
-        endo = (n * args.steps / dte, endo_ms / args.steps)
-        run(d_chal, 0, d_resp, 1, tau)      # d_resp again holds the exact path's output (parity sample below)
+        return (n * args.steps / (time.perf_counter() - te), k_ms / args.steps)
+    endo = direct = None
+    if not args.exact_only:
+        if not curve.startswith("mnt"):
+            endo = side_line(ENDO)
+        direct = side_line(DIRECT)
+        run(d_chal, 0, d_resp, 1, tau)      # d_resp again holds the value path's output (parity sample below)
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -630,7 +638,8 @@ def main():
         pmc, pmc_src = pmc_for(tag, args.config)
         traffic = pmc["hbm_bytes_per_launch"] if pmc else None
         traffic_raw = pmc.get("hbm_bytes_per_launch_raw_fetch") if pmc else None
-        macs = macs_per_update(curve, group, endo=False)
+        probed = probe_ms > 0     # Auto's membership probe ran and, the vector being genuine, the endomorphism kernel followed
+        macs = macs_per_update(curve, group, endo=probed)
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": pmc_src,
                 "traffic_ratio": (traffic / (algo * n)) if traffic else None,
@@ -641,7 +650,7 @@ def main():
                                 "profiles/r03_ubench_fetch.txt); Infinity-Cache hits are counted",
                 "algorithmic_bytes_per_update": algo, "updates_per_launch": n,
                 "kernel": "window_scalar_mul_kernel<%s>" % tag, "kernel_ms": smul_ms / args.steps,
-                "normalize_kernel_ms": norm_ms / args.steps,
+                "normalize_kernel_ms": norm_ms / args.steps, "membership_probe_ms": probe_ms / args.steps,
                 "macs_per_update": macs, "alu_peak_mac_per_s": MAC_PEAK,
                 "alu_frac": (macs * n / kernel_s / MAC_PEAK) if macs else None,
                 "note": "big-integer arithmetic: the kernel is bound by integer-multiplier issue, not by HBM — alu_frac (32x32->64 "
@@ -660,9 +669,15 @@ def main():
             "roofline": roof,
             "device_busy_frac_per_rank": busy,
             "cpu_baseline": base,
-            "value_path": "BatchExpMode::Auto with CheckForCorrectness::No (the operator's contribute default): plain signed-window "
-                          "multiplication, exact for ANY curve point",
+            "value_path": "BatchExpMode::Auto with CheckForCorrectness::No (the operator's contribute default), exact for ANY curve "
+                          "point: " + ("batched membership probe of the vector (2^-128, inside every step), then the endomorphism "
+                                       "(GLV / GLS) window kernel since every element passed" if probed else "plain signed-window multiplication"),
         }
+        if direct:
+            dm = macs_per_update(curve, group, endo=False)
+            out["direct_path"] = {"value": direct[0], "unit": "G1 point-updates/s (this rank)", "kernel_ms": direct[1],
+                                  "alu_frac": (dm * n / (direct[1] / 1e3) / MAC_PEAK) if dm else None, "macs_per_update": dm,
+                                  "batch_exp_mode": "Direct (plain signed windows, no probe; what Auto falls back to when the probe fails)"}
         if endo:
             em = macs_per_update(curve, group, endo=True)
             out["endomorphism_path"] = {"value": endo[0], "unit": "G1 point-updates/s (this rank)", "kernel_ms": endo[1],
@@ -679,19 +694,23 @@ def main():
             p2, _ = pmc_for(KERNEL_TAG[(c2, g2)], args.config)
             # BLS12-377 G2 under default flags: Auto probes the vector and, every element being a subgroup element here, the kernel
             # that runs (and is timed) is the GLS one
-            probed_endo = (c2, g2) == ("bls12_377", 2) and t2["subgroup_ms"] > 0
+            probed_endo = t2["subgroup_ms"] > 0
             m2 = macs_per_update(c2, g2, endo=probed_endo)
             entry = {"updates_per_s": n2 / ((t2["scalar_mul_ms"] + t2["normalize_ms"] + t2["subgroup_ms"]) / 1e3), "kernel_ms": t2["scalar_mul_ms"],
                      "normalize_kernel_ms": t2["normalize_ms"], "membership_probe_ms": t2["subgroup_ms"], "points": n2,
                      "algorithmic_bytes_per_update": 3 * cs2,
                      "hbm_frac": 3 * cs2 * n2 / (t2["scalar_mul_ms"] / 1e3) / 1e9 / HBM_PEAK_GBS,
                      "alu_frac": (m2 * n2 / (t2["scalar_mul_ms"] / 1e3) / MAC_PEAK) if m2 else None, "macs_per_update": m2,
-                     "path": "GLS after the membership probe (BatchExpMode::Auto)" if probed_endo else "plain windows",
+                     "path": "endomorphism (GLV / GLS) kernel after the batched membership probe (BatchExpMode::Auto)" if probed_endo else "plain windows",
                      "traffic_ratio": (p2["hbm_bytes_per_launch"] / (3 * cs2 * n2)) if p2 else None}
             if (not c2.startswith("mnt") or g2 == 2) and not args.exact_only:      # MNT: GLS on the twists (G2) only
                 run2(dc, 0, dr, 1, tau, ENDO)
                 entry["endomorphism_updates_per_s"] = n2 / (pkg.phase1_cli.last_timing(dev)["kernel_ms"] / 1e3)
                 entry["endomorphism_kernel_ms"] = pkg.phase1_cli.last_timing(dev)["scalar_mul_ms"]
+            if not args.exact_only:
+                run2(dc, 0, dr, 1, tau, DIRECT)
+                entry["direct_updates_per_s"] = n2 / (pkg.phase1_cli.last_timing(dev)["kernel_ms"] / 1e3)
+                entry["direct_kernel_ms"] = pkg.phase1_cli.last_timing(dev)["scalar_mul_ms"]
             others["%s_G%d" % (c2, g2)] = entry
             del dc, dr
         if others:
@@ -704,7 +723,7 @@ def main():
             nidx = 1 << (cfg["log2_chunk"] if args.log2_points is None else lg)
             cb["projected_chunk_seconds"] = nidx / cb["value"]
             ex = out["extras"]
-            for k in ("contribute_chunk", "contribute_chunk_exact"):
+            for k in ("contribute_chunk", "contribute_chunk_exact", "contribute_chunk_direct"):
                 if k in ex:
                     ex[k]["vs_cpu_all_cores"] = cb["projected_chunk_seconds"] / ex[k]["seconds"]
                     ex[k]["vs_cpu_all_cores_device_time"] = cb["projected_chunk_seconds"] / (ex[k]["device_ms"] / 1e3)

@@ -245,6 +245,11 @@ int enqueue_subgroup_kernels(DeviceCtx *c, int curve, int group, const GroupOps 
 int run_subgroup_check_dev(DeviceCtx *c, int curve, int group, const GroupOps *ops, const uint8_t *d_in, int cin, uint64_t n,
                            const Err &err);
 int flush_pending_copy(DeviceCtx *c, const Err &err);
+int run_batched_subgroup_dev(DeviceCtx *c, int curve, int group, const GroupOps *ops, const uint8_t *d_in, int cin, uint64_t n,
+                             const Err &err);
+bool use_batched_subgroup();
+bool cofactor_is_one(int curve, int group);
+constexpr uint64_t BATCHED_SUBGROUP_MIN = 1ull << 12;
 
 // One vector on device-resident buffers; caller holds the device mutex and has set the device.
 // check_input (setup_utils::CheckForCorrectness): bit 0 = non-zero, bit 1 = in the prime-order subgroup (and on the curve)
@@ -261,11 +266,16 @@ int run_apply_powers_dev(DeviceCtx *c, int curve, int group, const GroupOps *ops
     }
     if (use_endo == 2) {   // Auto, membership unknown: probe where the test is cheap next to the saving
         use_endo = 0;
-        if (ops->membership_cheap && n) {
+        // long vectors: the batched test (2^-128, setup-utils' SubgroupCheckMode::Batched) costs about one pass of bucket
+        // additions — a fifth of what the endomorphism saves on BLS12-377 G1, less elsewhere; short ones: the exact test
+        // where it is cheap (BLS12-377 G2)
+        const bool batched = ops->has_endo_mul && n > BATCHED_SUBGROUP_MIN && use_batched_subgroup() && !cin;
+        if ((batched || ops->membership_cheap) && n) {
             // "not a subgroup vector" (or not even valid points: the plain path then reports them as it always did) selects
             // the plain path; anything else — a HIP error, a failed allocation — is the caller's to see
             char pmsg[200] = {0};
-            const int prc = run_subgroup_check_dev(c, curve, group, ops, d_in, cin, n, Err{pmsg, sizeof(pmsg)});
+            const int prc = batched ? run_batched_subgroup_dev(c, curve, group, ops, d_in, cin, n, Err{pmsg, sizeof(pmsg)})
+                                    : run_subgroup_check_dev(c, curve, group, ops, d_in, cin, n, Err{pmsg, sizeof(pmsg)});
             if (prc == PTAU_OK) use_endo = 1;
             else if (prc != PTAU_E_NOT_IN_SUBGROUP && prc != PTAU_E_POINT && prc != PTAU_E_POINT_AT_INFINITY)
                 return err.fail(prc, "membership probe of BatchExpMode::Auto: %s", pmsg);
@@ -405,11 +415,15 @@ using ptau::msm_plan;
 // fuse (with defer_tail, PRF scalars and both sums): the membership-fused form — msm_plan's comment has the argument.  Every
 // bucket sum of both sums is normalised and put through the group's exact membership test (enqueue_subgroup_kernels); a failure
 // lands in the tail's error word as PTAU_E_NOT_IN_SUBGROUP.  Sum A covers points 0 .. n-1, sum B points 1 .. n.
-struct MsmFuse { int curve, group; };
+// only: nothing but the membership verdict is wanted (the stand-alone batched test, run_batched_subgroup_dev): one sum over
+// n scalars and n points, no reduction of the buckets, synchronous.
+struct MsmFuse { int curve, group; bool only = false; };
 int run_msm_bucket_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, int cin, uint64_t n, ptau::ScalarSource src,
                        uint8_t *out_a, uint8_t *out_b, int cout, const Err &err, bool defer_tail = false,
                        const MsmFuse *fuse = nullptr) {
-    if (fuse && !(defer_tail && src.mode == ptau::SCALAR_PRF && out_b)) return err.fail(PTAU_E_ARG, "membership-fused MSM: wrong call form");
+    if (fuse && !(src.mode == ptau::SCALAR_PRF && (fuse->only ? (!defer_tail && !out_b) : (defer_tail && out_b != nullptr))))
+        return err.fail(PTAU_E_ARG, "membership-fused MSM: wrong call form");
+    const bool only = fuse && fuse->only;
     const int test_cost = fuse ? std::max(1, ops->subgroup_cost_adds) : 0;
     if (c->tail.active) {   // left behind by a call that failed: its results are of no interest, its kernels must be done
         HIP_TRY(hipStreamSynchronize(c->tail_stream));
@@ -450,7 +464,7 @@ int run_msm_bucket_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, i
     int *d_err = defer_tail ? (int *)(c->t_buf + TB_ERR) : c->d_err;
     hipStream_t ts = c->stream;   // the stream of the tail kernels
     HIP_TRY(hipMemsetAsync(d_err, 0, sizeof(int), c->stream));
-    HIP_TRY(hipEventRecord(defer_tail ? c->tev[0] : c->ev[0], c->stream));
+    HIP_TRY(hipEventRecord(defer_tail || only ? c->tev[0] : c->ev[0], c->stream));   // (the membership kernels use ev[0] / ev[1])
     uint64_t li = 0;
     for (uint64_t off = 0; off < n || (n == 0 && li == 0); off += MSM_SLICE_POINTS, li++) {
         const uint64_t m = std::min(MSM_SLICE_POINTS, n - off);
@@ -484,6 +498,7 @@ int run_msm_bucket_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, i
         if (fuse && (rc = enqueue_subgroup_kernels(c, fuse->curve, fuse->group, ops, (const uint8_t *)c->bk_bytes, 0, (uint64_t)nsum * wb, err, d_err)))
             return rc;
         if (defer_tail && last_slice) HIP_TRY(hipEventRecord(c->tev[1], c->stream));
+        if (only) continue;
         // rows = nsum * W windows from here on
         const uint32_t rows = (uint32_t)(nsum * pl.W);
         uint32_t cols = pl.B / pl.seg;
@@ -496,6 +511,20 @@ int run_msm_bucket_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, i
             cols = T;
         }
         ops->msm_horner(ts, cur, totals + (size_t)li * ops->jac_bytes, pl, nsum, nslice);   // sum s -> totals[s * nslice + li]
+    }
+    if (only) {
+        HIP_TRY(hipEventRecord(c->tev[1], c->stream));
+        int bits = 0;
+        HIP_TRY(hipMemcpyAsync(&bits, d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipGetLastError());
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, c->tev[0], c->tev[1]));
+        c->timing.kernel_ms += ms;
+        c->busy_ms += ms;
+        c->timing.subgroup_ms += ms;
+        c->timing.points += n;
+        return errbits_to_code(bits, err);
     }
     uint8_t *fin = totals + (size_t)nsum * nslice * ops->jac_bytes;
     for (int sidx = 0; sidx < nsum; sidx++)
@@ -612,7 +641,6 @@ int finish_msm_tail(DeviceCtx *c, const Err &err, hipEvent_t *main_end) {
 }
 
 // PTAU_BATCHED_SUBGROUP=0: Auto / Batched run the exact per-element membership test everywhere (A/B runs).
-constexpr uint64_t BATCHED_SUBGROUP_MIN = 1ull << 12;
 bool use_batched_subgroup() {
     static const bool v = [] {
         const char *e = getenv("PTAU_BATCHED_SUBGROUP");
@@ -637,6 +665,37 @@ int run_msm_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, int cin,
     int rc = run_msm_naive_dev(c, ops, d_in, cin, n, src, out_a, cout, err);
     if (rc || !out_b) return rc;
     return run_msm_naive_dev(c, ops, d_in + isz, cin, n, src, out_b, cout, err);
+}
+
+// The batched membership test on its own (setup-utils check_subgroup, SubgroupCheckMode::Batched, SECURITY_PARAM = 128):
+// every element lands in W random buckets (one per window of a fresh 128-bit-seeded PRF scalar), the bucket sums go through
+// the group's exact test.  msm_plan's comment has the argument; a vector with an element outside the subgroup passes with
+// probability <= 2^-128.  Uncompressed input gets its on-curve test first.  Caller holds the device mutex.
+int run_batched_subgroup_dev(DeviceCtx *c, int curve, int group, const GroupOps *ops, const uint8_t *d_in, int cin, uint64_t n,
+                             const Err &err) {
+    if (!n) return PTAU_OK;
+    if (cofactor_is_one(curve, group)) return run_subgroup_check_dev(c, curve, group, ops, d_in, cin, n, err);
+    uint64_t seed[2];
+    FILE *f = fopen("/dev/urandom", "rb");
+    if (!f || fread(seed, 1, 16, f) != 16) {
+        if (f) fclose(f);
+        return err.fail(PTAU_E_IO, "cannot read /dev/urandom for the batched subgroup check");
+    }
+    fclose(f);
+    if (!cin) {   // the bucket sums of points that are not on the curve would mean nothing
+        HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
+        ops->on_curve(c->stream, d_in, n, c->d_err);
+        int bits = 0;
+        HIP_TRY(hipMemcpyAsync(&bits, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipGetLastError());
+        int rc = errbits_to_code(bits, err);
+        if (rc) return rc;
+    }
+    const MsmFuse fz{curve, group, true};
+    uint8_t unused[8];
+    return run_msm_bucket_dev(c, ops, d_in, cin, n, ptau::ScalarSource{ptau::SCALAR_PRF, nullptr, seed[0], seed[1], 0}, unused, nullptr, 0,
+                              err, false, &fz);
 }
 
 // PTAU_SUBGROUP=direct forces the [r]P == O form on every curve (A/B runs; the accept/reject set is the same).

@@ -951,9 +951,13 @@ struct MsmPlan {
 // subgroup check of setup-utils (SubgroupCheckMode::Batched, SECURITY_PARAM = 128): a point outside the subgroup lands, in
 // each window independently, in a uniformly random bucket (or in none, digit 0) and that window's test passes only if its image
 // in the cofactor group is cancelled by what the other points left in exactly that bucket: probability <= 2^-(c-1) per
-// window.  The plan therefore takes W = ceil(128 / (c - 1)) FULL windows — scalars of W c - 1 random bits (`bits`), which is
-// also a valid (longer) coefficient of the random linear combination — and weighs a bucket with the cost of its test
-// (bucket_test_cost, in mixed additions).
+// window: the signed digit is uniform over the 2^c residues whatever the carry from below, and at most two of them (+m, -m
+// of the one bucket holding the cancelling image; or the single residue 0 when every bucket is clean without the point) let
+// the window pass.  The top window holds one random bit less (2^-(c-2)).  The plan therefore takes W = ceil(129 / (c - 1))
+// windows of scalars with W c - 1 random bits (`bits`) — false-accept probability <= 2^-(W (c-1) - 1) <= 2^-128 — which are
+// also valid (longer) coefficients of the random linear combination, and weighs a bucket with the cost of its test
+// (bucket_test_cost, in mixed additions).  Both sums of power_pairs are tested: A holds points 0 .. n-2, B points 1 .. n-1,
+// each placed by an independent rho.
 struct MsmPlanEx : MsmPlan { int bits; };
 inline MsmPlanEx msm_plan(uint64_t m, int scalar_bits, int force_c = 0, int bucket_test_cost = 0) {
     MsmPlanEx best{};
@@ -965,7 +969,7 @@ inline MsmPlanEx msm_plan(uint64_t m, int scalar_bits, int force_c = 0, int buck
         bool balanced;
         if (bucket_test_cost > 0) {
             if (c < 3) continue;
-            W = (128 + c - 2) / (c - 1);
+            W = (129 + c - 2) / (c - 1);
             bits = W * c - 1;
             if (bits > PRF_MAX_BITS) continue;
             balanced = true;
@@ -1655,6 +1659,8 @@ struct GroupOps {
     // the membership test costs a small fraction of what the endomorphism multiplication saves over the plain one (BLS12-377
     // G2: 64 doublings against 188): BatchExpMode::Auto probes the vector and takes the GLS path when every element passes
     bool membership_cheap;
+    // the group has an endomorphism-accelerated multiplication at all (GLV / GLS; use_glv of window_scalar_mul is honoured)
+    bool has_endo_mul;
     // membership through psi (MNT twists): K1 with the fixed scalar psi_scalar (fr_limbs32 words), then psi_check on its result
     const uint32_t *psi_scalar;
     void (*psi_check)(hipStream_t, const uint8_t *in, int cin, const void *scratch, uint64_t n, int *err);
@@ -1874,6 +1880,8 @@ struct Launch {
         o.endo_subgroup = G::J::CfgT::ENDO_KIND != 0 ? endo_subgroup : nullptr;
         o.subgroup_via_glv = G::J::CfgT::GLV_KIND == 2;
         o.membership_cheap = G::J::CfgT::ENDO_KIND == 2 && Fr::N == 8;
+        o.has_endo_mul = G::J::CfgT::GLV_KIND != 0 || (G::J::CfgT::ENDO_KIND == 2 && Fr::N == 8);
+        if constexpr (!std::is_void_v<GA>) o.has_endo_mul = o.has_endo_mul || GA::HAS_GLS;
         if constexpr (G::J::CfgT::PSI_KIND == 1) {
             static_assert(sizeof(G::J::CfgT::PSI_N) / 4 == Fr::N, "psi scalar must have the scalar field's word count");
             o.psi_scalar = G::J::CfgT::PSI_N;

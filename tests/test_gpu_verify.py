@@ -594,3 +594,36 @@ def test_batched_subgroup_check_through_the_msm_buckets(name, pkg):
     # the library keeps working after the rejected calls (a tail left pending by a failed call is discarded)
     nc = pkg.phase1_cli.verification_and_decompress(ch0, bytes(resp), prm, ratio_check=True)
     assert nc[:64] == pkg.calculate_hash(bytes(resp))
+
+
+@pytest.mark.parametrize("name,group", [("bls12_377", 1), ("bls12_377", 2), ("bw6", 1), ("mnt4_753", 2)])
+def test_auto_probe_batched_on_long_vectors(name, group, pkg, cref):
+    """BatchExpMode::Auto on more than 2^12 unchecked elements probes the vector with the batched membership test (random
+    bucket sums, each tested exactly; capi.hip run_batched_subgroup_dev) and takes the endomorphism path only when it passes.
+    A genuine vector gives the bytes of Direct and of the oracle; with ONE element outside the subgroup anywhere in it (first,
+    middle, last; a cofactor-only point) the probe must fail and the plain path's exact bytes come out — compared with Direct
+    over the whole vector and with the oracle around the planted element."""
+    c = CURVES[name]
+    G = Group(c, group)
+    rng = random.Random(77 + group)
+    n = 4096 + 200
+    usz = G.uncomp_size
+    gen = serde.write_point(G, G.gen, False)
+    s = rng.randrange(2, c.r)
+    vec = pkg.phase1_cli.apply_powers(name, group, gen * n, n, 0, s, None, False, False, batch_exp_mode=pkg.BatchExpMode.Direct)
+    tau, coeff = rng.randrange(c.r), rng.randrange(1, c.r)
+    exp = pkg.phase1_cli.apply_powers(name, group, vec, n, 11, tau, coeff, False, True, batch_exp_mode=pkg.BatchExpMode.Direct)
+    got = pkg.phase1_cli.apply_powers(name, group, vec, n, 11, tau, coeff, False, True, batch_exp_mode=pkg.BatchExpMode.Auto)
+    assert pkg.phase1_cli.last_timing(0)["subgroup_ms"] > 0      # the probe ran
+    assert got == exp
+    csz = G.comp_size
+    assert got[:8 * csz] == cref.apply_powers(name, group, vec[:8 * usz], 8, 11, tau, coeff, False, True)
+    off = _off_subgroup_point(G, rng)
+    for pos, pt in ((0, off), (n // 2 + 1, off), (n - 1, off), (1234, G.mul(off, c.r))):
+        bad = bytearray(vec)
+        bad[pos * usz:(pos + 1) * usz] = serde.write_point(G, pt, False)
+        exp = pkg.phase1_cli.apply_powers(name, group, bytes(bad), n, 11, tau, coeff, False, True, batch_exp_mode=pkg.BatchExpMode.Direct)
+        got = pkg.phase1_cli.apply_powers(name, group, bytes(bad), n, 11, tau, coeff, False, True, batch_exp_mode=pkg.BatchExpMode.Auto)
+        assert got == exp, (name, group, pos)
+        lo = max(0, min(pos - 1, n - 3))
+        assert got[lo * csz:(lo + 3) * csz] == cref.apply_powers(name, group, bytes(bad[lo * usz:(lo + 3) * usz]), 3, 11 + lo, tau, coeff, False, True)
