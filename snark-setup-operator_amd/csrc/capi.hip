@@ -155,17 +155,23 @@ struct DeviceCtx {
     hipEvent_t tev[4] = {};   // head start, head end (main stream), tail end (tail stream), buckets consumed (main stream)
     void *bk_bytes = nullptr, *bk_pre = nullptr;   // membership-fused MSM: the bucket sums as uncompressed points, inversion scratch
     size_t bk_bytes_cap = 0, bk_pre_cap = 0;
+    // the bucket tests run on the tail stream, beside whatever the main stream does next: their own K1 buffers and scalar
+    void *bk_scratch = nullptr, *bk_wtab = nullptr;
+    size_t bk_scratch_cap = 0, bk_wtab_cap = 0;
+    uint32_t *bk_table = nullptr;
     uint8_t *t_buf = nullptr;   // [pre 8 KB | results 4 KB | err 16 B]
     struct PendingTail {
         bool active = false;
         uint8_t *out_a = nullptr, *out_b = nullptr;
         int osz = 0;
         uint64_t points = 0;
+        bool probe = false;   // a membership probe: its main-stream time is membership time, there are no sums to fetch
     } tail;
+    int cus = 0;   // compute units of the device
     ptau_timing timing = {};
     double busy_ms = 0;   // kernel time since the library was loaded, every call on this device (under mu)
 };
-constexpr size_t TB_PRE = 0, TB_SMALL = 8192, TB_ERR = 12288, TB_SIZE = 16384;
+constexpr size_t TB_PRE = 0, TB_SMALL = 8192, TB_ERR = 12288, TB_TABLE = 12544, TB_SIZE = 16384;
 DeviceCtx g_ctx[MAX_DEVICES];
 // second context per device (own stream and small buffers) for the lone beta_g2 element of a contribution: its update is
 // ONE thread's scalar multiplication (8 ms on BLS12-377, ~130 ms on MNT6 G2) and runs beside the four vectors.  Only used
@@ -213,11 +219,16 @@ int ensure_ctx(int device, DeviceCtx *&c, const Err &err, bool side = false) {
     c->cev[1] = evs[7];
     for (int i = 0; i < 4; i++) c->tev[i] = evs[8 + i];
     c->t_buf = (uint8_t *)bufs[4];
+    c->bk_table = (uint32_t *)(c->t_buf + TB_TABLE);
     c->d_table = (uint32_t *)bufs[0];
     c->d_err = (int *)bufs[1];
     c->d_small = bufs[2];
     c->s_buf = (uint8_t *)bufs[3];
     c->tail = DeviceCtx::PendingTail{};
+    {
+        hipDeviceProp_t prop;
+        c->cus = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256;
+    }
     c->ready = true;
     return PTAU_OK;
 }
@@ -241,13 +252,15 @@ int errbits_to_code(int bits, const Err &err) {
 }
 
 int enqueue_subgroup_kernels(DeviceCtx *c, int curve, int group, const GroupOps *ops, const uint8_t *d_in, int cin, uint64_t n,
-                             const Err &err, int *d_err_override = nullptr);
+                             const Err &err, bool side = false);
 int run_subgroup_check_dev(DeviceCtx *c, int curve, int group, const GroupOps *ops, const uint8_t *d_in, int cin, uint64_t n,
                            const Err &err);
 int flush_pending_copy(DeviceCtx *c, const Err &err);
-int run_batched_subgroup_dev(DeviceCtx *c, int curve, int group, const GroupOps *ops, const uint8_t *d_in, int cin, uint64_t n,
-                             const Err &err);
+int enqueue_batched_subgroup_dev(DeviceCtx *c, int curve, int group, const GroupOps *ops, const uint8_t *d_in, int cin, uint64_t n,
+                                 const Err &err);
+int finish_msm_tail(DeviceCtx *c, const Err &err, hipEvent_t *main_end);
 bool use_batched_subgroup();
+bool use_endo_subgroup();
 bool cofactor_is_one(int curve, int group);
 constexpr uint64_t BATCHED_SUBGROUP_MIN = 1ull << 12;
 
@@ -264,18 +277,27 @@ int run_apply_powers_dev(DeviceCtx *c, int curve, int group, const GroupOps *ops
         int rc = run_subgroup_check_dev(c, curve, group, ops, d_in, cin, n, err);
         if (rc) return rc;
     }
-    if (use_endo == 2) {   // Auto, membership unknown: probe where the test is cheap next to the saving
+    bool speculative = false;
+    if (use_endo == 2) {   // Auto, membership unknown
         use_endo = 0;
-        // long vectors: the batched test (2^-128, setup-utils' SubgroupCheckMode::Batched) costs about one pass of bucket
-        // additions — a fifth of what the endomorphism saves on BLS12-377 G1, less elsewhere; short ones: the exact test
-        // where it is cheap (BLS12-377 G2)
-        const bool batched = ops->has_endo_mul && n > BATCHED_SUBGROUP_MIN && use_batched_subgroup() && !cin;
-        if ((batched || ops->membership_cheap) && n) {
+        // long vectors: the batched test (2^-128, setup-utils' SubgroupCheckMode::Batched).  Its bucket sums cost about one pass
+        // of mixed additions on the main stream; the tests of those sums are a latency-bound launch (a few thousand scalar
+        // multiplications: 1 ms on BLS12-377 G1, 10 ms on BW6-761, 35-60 ms on the MNT twists) on the tail stream, and the
+        // endomorphism kernel is queued behind the sums at once — SPECULATIVELY, beside the tests.  The verdict is read when
+        // both are done; if it is "not a subgroup vector" (or not even valid points) the result is thrown away and the plain
+        // path runs, which reports bad points as it always did.  Short vectors: the exact test where it is cheap (BLS12-377 G2).
+        const bool batched = ops->has_endo_mul && n > BATCHED_SUBGROUP_MIN && use_batched_subgroup() && !cin &&
+                             !cofactor_is_one(curve, group);
+        if (batched) {
+            int rc = enqueue_batched_subgroup_dev(c, curve, group, ops, d_in, cin, n, err);
+            if (rc) return rc;
+            speculative = true;
+            use_endo = 1;
+        } else if (ops->membership_cheap && n) {
             // "not a subgroup vector" (or not even valid points: the plain path then reports them as it always did) selects
             // the plain path; anything else — a HIP error, a failed allocation — is the caller's to see
             char pmsg[200] = {0};
-            const int prc = batched ? run_batched_subgroup_dev(c, curve, group, ops, d_in, cin, n, Err{pmsg, sizeof(pmsg)})
-                                    : run_subgroup_check_dev(c, curve, group, ops, d_in, cin, n, Err{pmsg, sizeof(pmsg)});
+            const int prc = run_subgroup_check_dev(c, curve, group, ops, d_in, cin, n, Err{pmsg, sizeof(pmsg)});
             if (prc == PTAU_OK) use_endo = 1;
             else if (prc != PTAU_E_NOT_IN_SUBGROUP && prc != PTAU_E_POINT && prc != PTAU_E_POINT_AT_INFINITY)
                 return err.fail(prc, "membership probe of BatchExpMode::Auto: %s", pmsg);
@@ -318,6 +340,17 @@ int run_apply_powers_dev(DeviceCtx *c, int curve, int group, const GroupOps *ops
         c->timing.normalize_ms += b;
         c->timing.kernel_ms += a + b;
         c->busy_ms += a + b;
+        if (speculative) {   // the probe's verdict (its tests ran beside the launch just waited for)
+            speculative = false;
+            char pmsg[200] = {0};
+            const int prc = finish_msm_tail(c, Err{pmsg, sizeof(pmsg)}, &c->ev[2]);
+            if (prc == PTAU_E_NOT_IN_SUBGROUP || prc == PTAU_E_POINT || prc == PTAU_E_POINT_AT_INFINITY) {
+                use_endo = 0;          // not a subgroup vector: everything again on the plain path
+                off = 0 - launch_cap;  // (the loop's increment brings it back to 0)
+                continue;
+            }
+            if (prc) return err.fail(prc, "membership probe of BatchExpMode::Auto: %s", pmsg);
+        }
         c->timing.points += m;
         if ((rc = errbits_to_code(bits, err))) return rc;
     }
@@ -356,41 +389,45 @@ int run_apply_powers_host(DeviceCtx *c, int curve, int group, const GroupOps *op
 }
 
 // Exclusive prefix sums over m bucket counts: offsets[0..m] (entries; offsets[m] = total), cursor[j] = offsets[j]
-// (the scatter pass bumps the cursor with atomics) and run_offsets[0..m] over ceil(count / MSM_RUN) (the runs the
-// accumulate pass works on).  One workgroup: m is at most a few hundred thousand.
+// (the scatter pass bumps the cursor with atomics) and run_offsets[0..m] over the partial-sum slots of every bucket
+// (ptau::msm_bucket_parts: the entry-aligned runs of run_len that touch it).  One workgroup: m is at most a few hundred thousand.
 __global__ void __launch_bounds__(1024) exclusive_scan_kernel(uint32_t *__restrict__ counts_cursor, uint32_t *__restrict__ offsets,
-                                                              uint32_t *__restrict__ run_offsets, uint32_t m) {
-    __shared__ uint32_t part[1024], rpart[1024];
+                                                              uint32_t *__restrict__ run_offsets, uint32_t m, uint32_t run_len) {
+    __shared__ uint32_t part[1024];
     const uint32_t t = threadIdx.x, per = (m + 1023u) / 1024u;
     const uint32_t lo = t * per < m ? t * per : m, hi = lo + per < m ? lo + per : m;
-    uint32_t sum = 0, rsum = 0;
+    auto scan = [&](uint32_t mine) {   // exclusive prefix of `mine` over the workgroup; part[1023] = the total afterwards
+        __syncthreads();
+        part[t] = mine;
+        __syncthreads();
+        for (uint32_t d = 1; d < 1024; d <<= 1) {   // Hillis-Steele inclusive scan of the 1024 partials
+            const uint32_t v = t >= d ? part[t - d] : 0;
+            __syncthreads();
+            part[t] += v;
+            __syncthreads();
+        }
+        return t ? part[t - 1] : 0u;
+    };
+    uint32_t sum = 0;
+    for (uint32_t j = lo; j < hi; j++) sum += counts_cursor[j];
+    const uint32_t base = scan(sum);
+    if (t == 1023) offsets[m] = part[1023];
+    uint32_t run = base, rsum = 0;
     for (uint32_t j = lo; j < hi; j++) {
         const uint32_t cnt = counts_cursor[j];
-        sum += cnt;
-        rsum += (cnt + ptau::MSM_RUN - 1) / ptau::MSM_RUN;
+        rsum += ptau::msm_bucket_parts(run, cnt, run_len);
+        run += cnt;
     }
-    part[t] = sum;
-    rpart[t] = rsum;
-    __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {   // Hillis-Steele inclusive scan of the 1024 partials
-        const uint32_t v = t >= d ? part[t - d] : 0, rv = t >= d ? rpart[t - d] : 0;
-        __syncthreads();
-        part[t] += v;
-        rpart[t] += rv;
-        __syncthreads();
-    }
-    uint32_t run = t ? part[t - 1] : 0, rrun = t ? rpart[t - 1] : 0;
+    uint32_t rrun = scan(rsum);
+    if (t == 1023) run_offsets[m] = part[1023];
+    run = base;
     for (uint32_t j = lo; j < hi; j++) {
         const uint32_t cnt = counts_cursor[j];
         offsets[j] = run;
         run_offsets[j] = rrun;
         counts_cursor[j] = run;
+        rrun += ptau::msm_bucket_parts(run, cnt, run_len);
         run += cnt;
-        rrun += (cnt + ptau::MSM_RUN - 1) / ptau::MSM_RUN;
-    }
-    if (t == 1023) {
-        offsets[m] = part[1023];
-        run_offsets[m] = rpart[1023];
     }
 }
 
@@ -410,21 +447,42 @@ using ptau::msm_plan;
 // sum_i k_i * P_i (i < n) -> ONE serialized affine point in host memory; with out_b also the SHIFTED sum
 // sum_i k_i * P_{i+1} (power_pairs: d_in must then hold n + 1 points).  Bucket method (K4); caller holds the
 // device mutex.
+// Entries per accumulate thread.  Every run costs the same (run_len mixed additions) and the pass takes
+// ceil(runs / resident lanes) rounds of them, so the run length is what makes the runs of a launch fill the resident lanes a
+// whole number of times: 11.5 M entries (2^20 points, 11 windows) on 131 k resident lanes are ONE round of 88-entry runs —
+// runs of 64 would be 1.4 rounds, i.e. two.  PTAU_MSM_RUN=<n> forces a length (A/B runs).
+uint32_t msm_run_length(const DeviceCtx *c, const GroupOps *ops, uint64_t m, const ptau::MsmPlan &pl) {
+    static const uint32_t forced = [] {
+        const char *e = getenv("PTAU_MSM_RUN");
+        const long v = e ? atol(e) : 0;
+        return (uint32_t)(v >= 8 && v <= 4096 ? v : 0);
+    }();
+    if (forced) return forced;
+    const uint64_t resident = (uint64_t)std::max(1, c->cus) * 512 / ops->msm_lanes_per_run;   // two waves per SIMD (199-256 VGPRs)
+    const uint64_t total = (uint64_t)pl.W * m;   // upper bound: zero digits drop out
+    const uint64_t k = std::max<uint64_t>(1, (total + resident * ptau::MSM_RUN_MAX - 1) / (resident * ptau::MSM_RUN_MAX));
+    const uint64_t len = (total + k * resident - 1) / (k * resident);
+    return (uint32_t)std::min<uint64_t>(ptau::MSM_RUN_MAX, std::max<uint64_t>(ptau::MSM_RUN, len));
+}
+
 // defer_tail: everything after the last slice's bucket sums goes to the tail stream and NOTHING is waited for; out_a / out_b
 // are written by finish_msm_tail(), which the caller must reach before the next MSM on this context.
-// fuse (with defer_tail, PRF scalars and both sums): the membership-fused form — msm_plan's comment has the argument.  Every
-// bucket sum of both sums is normalised and put through the group's exact membership test (enqueue_subgroup_kernels); a failure
-// lands in the tail's error word as PTAU_E_NOT_IN_SUBGROUP.  Sum A covers points 0 .. n-1, sum B points 1 .. n.
-// only: nothing but the membership verdict is wanted (the stand-alone batched test, run_batched_subgroup_dev): one sum over
-// n scalars and n points, no reduction of the buckets, synchronous.
+// fuse (PRF scalars): the membership-fused form — msm_plan's comment has the argument.  Every bucket sum is normalised and put
+// through the group's exact membership test (enqueue_subgroup_kernels) ON THE TAIL STREAM: a few thousand tests are a
+// latency-bound launch (one scalar multiplication per thread: ~1 ms on BLS12-377 G1, 10 ms on BW6-761, 35-60 ms on the MNT
+// twists) that runs beside whatever the main stream does next.  A failure lands in the tail's error word as
+// PTAU_E_NOT_IN_SUBGROUP.  With both sums (the verify path): sum A covers points 0 .. n-1, sum B points 1 .. n.
+// only: nothing but the membership verdict is wanted (the probe of BatchExpMode::Auto, run_batched_subgroup_dev): one sum over
+// n scalars and n points, no reduction of the buckets; finish_msm_tail() returns the verdict.
 struct MsmFuse { int curve, group; bool only = false; };
 int run_msm_bucket_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, int cin, uint64_t n, ptau::ScalarSource src,
                        uint8_t *out_a, uint8_t *out_b, int cout, const Err &err, bool defer_tail = false,
                        const MsmFuse *fuse = nullptr) {
-    if (fuse && !(src.mode == ptau::SCALAR_PRF && (fuse->only ? (!defer_tail && !out_b) : (defer_tail && out_b != nullptr))))
+    if (fuse && !(defer_tail && src.mode == ptau::SCALAR_PRF && (fuse->only ? !out_b : out_b != nullptr)))
         return err.fail(PTAU_E_ARG, "membership-fused MSM: wrong call form");
     const bool only = fuse && fuse->only;
     const int test_cost = fuse ? std::max(1, ops->subgroup_cost_adds) : 0;
+    const uint64_t resident_runs = (uint64_t)std::max(1, c->cus) * 512 / ops->msm_lanes_per_run;
     if (c->tail.active) {   // left behind by a call that failed: its results are of no interest, its kernels must be done
         HIP_TRY(hipStreamSynchronize(c->tail_stream));
         c->tail.active = false;
@@ -438,14 +496,14 @@ int run_msm_bucket_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, i
     // workspace carve-up (sized for the largest slice; W*B peaks at the largest c)
     size_t wb_max = 0, w_max = 0;
     for (uint64_t m : {cap, n % MSM_SLICE_POINTS ? n % MSM_SLICE_POINTS : cap}) {
-        const ptau::MsmPlan pl = msm_plan(std::max<uint64_t>(m, 1), scalar_bits, 0, test_cost);
+        const ptau::MsmPlan pl = msm_plan(std::max<uint64_t>(m, 1), scalar_bits, 0, test_cost, resident_runs);
         wb_max = std::max(wb_max, (size_t)pl.W * pl.B);
         w_max = std::max(w_max, (size_t)pl.W);
     }
     const size_t sz_aff = al((cap + 1) * ops->affine_bytes), sz_dig = al(w_max * cap * 4), sz_sorted = sz_dig,
                  sz_counts = al(wb_max * 4), sz_offsets = al((wb_max + 1) * 4), sz_buckets = al(nsum * wb_max * ops->jac_bytes),
                  sz_parts = sz_buckets, sz_totals = al((nsum * (nslice + 1) + 8) * ops->jac_bytes),
-                 sz_runs = al((wb_max + w_max * cap / ptau::MSM_RUN + 1) * ops->jac_bytes);   // <= one run per bucket + one per MSM_RUN entries
+                 sz_runs = al((wb_max + w_max * cap / ptau::MSM_RUN + 2) * ops->jac_bytes);   // <= one partial per bucket + one per run
     int rc;
     if ((rc = grow(c->msm_ws, c->msm_cap, sz_aff + sz_dig + sz_sorted + sz_counts + 2 * sz_offsets + sz_buckets + sz_parts + sz_totals + sz_runs, err)))
         return rc;
@@ -464,11 +522,17 @@ int run_msm_bucket_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, i
     int *d_err = defer_tail ? (int *)(c->t_buf + TB_ERR) : c->d_err;
     hipStream_t ts = c->stream;   // the stream of the tail kernels
     HIP_TRY(hipMemsetAsync(d_err, 0, sizeof(int), c->stream));
-    HIP_TRY(hipEventRecord(defer_tail || only ? c->tev[0] : c->ev[0], c->stream));   // (the membership kernels use ev[0] / ev[1])
+    if (fuse) {   // the fixed scalar of the bucket tests ([r] or [|t - 1|]), ahead of everything the tail stream will wait for
+        const bool via_psi = ops->psi_check && use_endo_subgroup();
+        HIP_TRY(hipMemcpyAsync(c->bk_table, via_psi ? ops->psi_scalar : ops->group_order, sizeof(uint32_t) * ops->fr_limbs32,
+                               hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_TRY(hipEventRecord(defer_tail ? c->tev[0] : c->ev[0], c->stream));
+    if (only && !cin) ops->on_curve(c->stream, d_in, n, d_err);   // bucket sums of points off the curve would mean nothing
     uint64_t li = 0;
     for (uint64_t off = 0; off < n || (n == 0 && li == 0); off += MSM_SLICE_POINTS, li++) {
         const uint64_t m = std::min(MSM_SLICE_POINTS, n - off);
-        const ptau::MsmPlanEx pl = msm_plan(std::max<uint64_t>(m, 1), scalar_bits, 0, test_cost);
+        const ptau::MsmPlanEx pl = msm_plan(std::max<uint64_t>(m, 1), scalar_bits, 0, test_cost, resident_runs);
         const uint64_t wb = (uint64_t)pl.W * pl.B;
         ptau::ScalarSource s2 = src;
         if (fuse) s2.prf_bits = pl.bits;
@@ -476,28 +540,36 @@ int run_msm_bucket_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, i
         s2.index_base += off;
         HIP_TRY(hipMemsetAsync(counts, 0, wb * 4, c->stream));
         ops->msm_prepare(c->stream, d_in + off * isz, cin, aff, dig, counts, m + (nsum - 1), m, s2, pl, d_err);
-        hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, c->stream, counts, offsets, run_offsets, (uint32_t)wb);
+        const uint32_t run_len = msm_run_length(c, ops, m, pl);
+        hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, c->stream, counts, offsets, run_offsets, (uint32_t)wb, run_len);
         if (m) hipLaunchKernelGGL(ptau::msm_scatter_kernel<0>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, dig, counts, sorted, m, pl);
-        const uint64_t max_runs = wb + (uint64_t)pl.W * m / ptau::MSM_RUN + 1;
+        const uint64_t max_runs = std::max<uint64_t>(1, ((uint64_t)pl.W * m + run_len - 1) / run_len);   // threads of the accumulate pass
         for (int sidx = 0; sidx < nsum; sidx++) {
-            ops->msm_accumulate(c->stream, aff, sorted, offsets, run_offsets, runs, (uint32_t)sidx, (uint32_t)wb, max_runs);
+            ops->msm_accumulate(c->stream, aff, sorted, offsets, run_offsets, runs, (uint32_t)sidx, (uint32_t)wb, max_runs, run_len);
             ops->msm_combine(c->stream, runs, run_offsets, buckets + (size_t)sidx * wb * ops->jac_bytes, wb);
         }
         const bool last_slice = off + MSM_SLICE_POINTS >= n;
-        if (fuse) {   // the bucket sums as points, before the reduction below reuses their memory
+        if (fuse) {   // the bucket sums as points (before the reduction below reuses their memory), their tests on the tail stream
             const uint64_t nb = (uint64_t)nsum * wb;
             if ((rc = grow(c->bk_bytes, c->bk_bytes_cap, nb * ops->uncomp, err))) return rc;
             if ((rc = grow(c->bk_pre, c->bk_pre_cap, nb * ops->fe_bytes, err))) return rc;
             ops->normalize(c->stream, buckets, c->bk_pre, (uint8_t *)c->bk_bytes, 0, nb, (nb + 3) / 4, 0, d_err);
-        }
-        if (defer_tail && last_slice) {   // last slice: the main stream is done with the buckets here
             HIP_TRY(hipEventRecord(c->tev[3], c->stream));
             HIP_TRY(hipStreamWaitEvent(c->tail_stream, c->tev[3], 0));
+            if ((rc = enqueue_subgroup_kernels(c, fuse->curve, fuse->group, ops, (const uint8_t *)c->bk_bytes, 0, nb, err, /*side=*/true))) return rc;
+            if (!last_slice) {   // the next slice reuses bk_bytes
+                HIP_TRY(hipEventRecord(c->tev[2], c->tail_stream));
+                HIP_TRY(hipStreamWaitEvent(c->stream, c->tev[2], 0));
+            }
+        }
+        if (defer_tail && last_slice) {   // last slice: the main stream is done with this MSM here
+            if (!fuse) {
+                HIP_TRY(hipEventRecord(c->tev[3], c->stream));
+                HIP_TRY(hipStreamWaitEvent(c->tail_stream, c->tev[3], 0));
+            }
+            HIP_TRY(hipEventRecord(c->tev[1], c->stream));
             ts = c->tail_stream;
         }
-        if (fuse && (rc = enqueue_subgroup_kernels(c, fuse->curve, fuse->group, ops, (const uint8_t *)c->bk_bytes, 0, (uint64_t)nsum * wb, err, d_err)))
-            return rc;
-        if (defer_tail && last_slice) HIP_TRY(hipEventRecord(c->tev[1], c->stream));
         if (only) continue;
         // rows = nsum * W windows from here on
         const uint32_t rows = (uint32_t)(nsum * pl.W);
@@ -512,32 +584,20 @@ int run_msm_bucket_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, i
         }
         ops->msm_horner(ts, cur, totals + (size_t)li * ops->jac_bytes, pl, nsum, nslice);   // sum s -> totals[s * nslice + li]
     }
-    if (only) {
-        HIP_TRY(hipEventRecord(c->tev[1], c->stream));
-        int bits = 0;
-        HIP_TRY(hipMemcpyAsync(&bits, d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        HIP_TRY(hipGetLastError());
-        float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, c->tev[0], c->tev[1]));
-        c->timing.kernel_ms += ms;
-        c->busy_ms += ms;
-        c->timing.subgroup_ms += ms;
-        c->timing.points += n;
-        return errbits_to_code(bits, err);
-    }
     uint8_t *fin = totals + (size_t)nsum * nslice * ops->jac_bytes;
-    for (int sidx = 0; sidx < nsum; sidx++)
-        ops->reduce_sum(ts, totals + (size_t)sidx * nslice * ops->jac_bytes, fin + (size_t)sidx * ops->jac_bytes, li, 1);
+    if (!only)
+        for (int sidx = 0; sidx < nsum; sidx++)
+            ops->reduce_sum(ts, totals + (size_t)sidx * nslice * ops->jac_bytes, fin + (size_t)sidx * ops->jac_bytes, li, 1);
     if (defer_tail) {
-        ops->normalize(ts, fin, c->t_buf + TB_PRE, c->t_buf + TB_SMALL, cout, nsum, nsum, 0, d_err);
+        if (!only) ops->normalize(ts, fin, c->t_buf + TB_PRE, c->t_buf + TB_SMALL, cout, nsum, nsum, 0, d_err);
         HIP_TRY(hipEventRecord(c->tev[2], ts));
         HIP_TRY(hipGetLastError());
         c->tail.active = true;
-        c->tail.out_a = out_a;
-        c->tail.out_b = out_b;
+        c->tail.out_a = only ? nullptr : out_a;
+        c->tail.out_b = only ? nullptr : out_b;
         c->tail.osz = osz;
-        c->tail.points = n * nsum;
+        c->tail.points = only ? 0 : n * nsum;
+        c->tail.probe = only;
         return PTAU_OK;
     }
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
@@ -624,7 +684,7 @@ int finish_msm_tail(DeviceCtx *c, const Err &err, hipEvent_t *main_end) {
     HIP_TRY(hipGetLastError());
     int bits = 0;
     HIP_TRY(hipMemcpy(&bits, c->t_buf + TB_ERR, sizeof(int), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(c->tail.out_a, c->t_buf + TB_SMALL, c->tail.osz, hipMemcpyDeviceToHost));
+    if (c->tail.out_a) HIP_TRY(hipMemcpy(c->tail.out_a, c->t_buf + TB_SMALL, c->tail.osz, hipMemcpyDeviceToHost));
     if (c->tail.out_b) HIP_TRY(hipMemcpy(c->tail.out_b, c->t_buf + TB_SMALL + c->tail.osz, c->tail.osz, hipMemcpyDeviceToHost));
     float head = 0, lat = 0, past = 0;
     HIP_TRY(hipEventElapsedTime(&head, c->tev[0], c->tev[1]));
@@ -634,7 +694,7 @@ int finish_msm_tail(DeviceCtx *c, const Err &err, hipEvent_t *main_end) {
     past = std::min(std::max(past, 0.0f), lat);
     c->timing.kernel_ms += head + past;
     c->busy_ms += head + past;
-    c->timing.msm_ms += head + past;
+    (c->tail.probe ? c->timing.subgroup_ms : c->timing.msm_ms) += head + past;
     c->timing.msm_tail_ms += lat;
     c->timing.points += c->tail.points;
     return errbits_to_code(bits, err);
@@ -671,10 +731,10 @@ int run_msm_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, int cin,
 // every element lands in W random buckets (one per window of a fresh 128-bit-seeded PRF scalar), the bucket sums go through
 // the group's exact test.  msm_plan's comment has the argument; a vector with an element outside the subgroup passes with
 // probability <= 2^-128.  Uncompressed input gets its on-curve test first.  Caller holds the device mutex.
-int run_batched_subgroup_dev(DeviceCtx *c, int curve, int group, const GroupOps *ops, const uint8_t *d_in, int cin, uint64_t n,
-                             const Err &err) {
-    if (!n) return PTAU_OK;
-    if (cofactor_is_one(curve, group)) return run_subgroup_check_dev(c, curve, group, ops, d_in, cin, n, err);
+// enqueue_...: nothing is waited for — the bucket sums are queued on the main stream, their tests on the tail stream, and
+// finish_msm_tail() returns the verdict; whatever the caller queues on the main stream in between runs beside the tests.
+int enqueue_batched_subgroup_dev(DeviceCtx *c, int curve, int group, const GroupOps *ops, const uint8_t *d_in, int cin, uint64_t n,
+                                 const Err &err) {
     uint64_t seed[2];
     FILE *f = fopen("/dev/urandom", "rb");
     if (!f || fread(seed, 1, 16, f) != 16) {
@@ -682,20 +742,18 @@ int run_batched_subgroup_dev(DeviceCtx *c, int curve, int group, const GroupOps 
         return err.fail(PTAU_E_IO, "cannot read /dev/urandom for the batched subgroup check");
     }
     fclose(f);
-    if (!cin) {   // the bucket sums of points that are not on the curve would mean nothing
-        HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
-        ops->on_curve(c->stream, d_in, n, c->d_err);
-        int bits = 0;
-        HIP_TRY(hipMemcpyAsync(&bits, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        HIP_TRY(hipGetLastError());
-        int rc = errbits_to_code(bits, err);
-        if (rc) return rc;
-    }
     const MsmFuse fz{curve, group, true};
-    uint8_t unused[8];
-    return run_msm_bucket_dev(c, ops, d_in, cin, n, ptau::ScalarSource{ptau::SCALAR_PRF, nullptr, seed[0], seed[1], 0}, unused, nullptr, 0,
-                              err, false, &fz);
+    return run_msm_bucket_dev(c, ops, d_in, cin, n, ptau::ScalarSource{ptau::SCALAR_PRF, nullptr, seed[0], seed[1], 0}, nullptr, nullptr, 0,
+                              err, true, &fz);
+}
+int run_batched_subgroup_dev(DeviceCtx *c, int curve, int group, const GroupOps *ops, const uint8_t *d_in, int cin, uint64_t n,
+                             const Err &err) {
+    if (!n) return PTAU_OK;
+    if (cofactor_is_one(curve, group)) return run_subgroup_check_dev(c, curve, group, ops, d_in, cin, n, err);
+    int rc = enqueue_batched_subgroup_dev(c, curve, group, ops, d_in, cin, n, err);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return finish_msm_tail(c, err, nullptr);
 }
 
 // PTAU_SUBGROUP=direct forces the [r]P == O form on every curve (A/B runs; the accept/reject set is the same).
@@ -716,37 +774,46 @@ bool cofactor_is_one(int curve, int group) {
 // Cofactor-1 groups (MNT G1) need only the on-curve test.  Caller holds the device mutex.
 // Enqueue only (no error-word reset, no synchronisation): events ev[0] / ev[1] bracket the membership kernels.
 int enqueue_subgroup_kernels(DeviceCtx *c, int curve, int group, const GroupOps *ops, const uint8_t *d_in, int cin, uint64_t n,
-                             const Err &err, int *d_err_override) {
-    int *const d_err = d_err_override ? d_err_override : c->d_err;
+                             const Err &err, bool side) {
+    // side: the bucket tests of a membership-fused MSM — tail stream, the tail's error word, their own K1 buffers and scalar
+    // (the main stream may be running the next vector's kernels, or K1 itself, at the same time); no timing events
+    int *const d_err = side ? (int *)(c->t_buf + TB_ERR) : c->d_err;
+    hipStream_t const st = side ? c->tail_stream : c->stream;
+    void *&scratch = side ? c->bk_scratch : c->scratch;
+    size_t &scratch_cap = side ? c->bk_scratch_cap : c->scratch_cap;
+    void *&wtab = side ? c->bk_wtab : c->wtab;
+    size_t &wtab_cap = side ? c->bk_wtab_cap : c->wtab_cap;
+    uint32_t *const d_table = side ? c->bk_table : c->d_table;
     const int isz = cin ? ops->comp : ops->uncomp;
     const uint64_t launch_cap =
         std::max<uint64_t>(256, std::min(MAX_LAUNCH_POINTS, MAX_WINDOW_TABLE_BYTES / (ptau::WINDOW_ENTRIES * ops->wtab_entry_bytes)));
     const bool via_psi = ops->psi_check && use_endo_subgroup();   // MNT twists: psi(P) == [t - 1]P, a half-length fixed scalar
-    HIP_TRY(hipMemcpyAsync(c->d_table, via_psi ? ops->psi_scalar : ops->group_order, sizeof(uint32_t) * ops->fr_limbs32,
-                           hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    if (!side)   // (side: the caller has loaded bk_table on the main stream, ahead of the event the tail stream waits for)
+        HIP_TRY(hipMemcpyAsync(d_table, via_psi ? ops->psi_scalar : ops->group_order, sizeof(uint32_t) * ops->fr_limbs32,
+                               hipMemcpyHostToDevice, st));
+    if (!side) HIP_TRY(hipEventRecord(c->ev[0], st));
     if (ops->endo_subgroup && use_endo_subgroup()) {
-        ops->endo_subgroup(c->stream, d_in, cin, n, d_err);   // on-curve test included
+        ops->endo_subgroup(st, d_in, cin, n, d_err);   // on-curve test included
     } else if (!cin) {
-        ops->on_curve(c->stream, d_in, n, d_err);
+        ops->on_curve(st, d_in, n, d_err);
     }
     if (!(ops->endo_subgroup && use_endo_subgroup()) && !cofactor_is_one(curve, group)) {
         for (uint64_t off = 0; off < n; off += launch_cap) {
             const uint64_t m = std::min(launch_cap, n - off);
             int rc;
-            if ((rc = grow(c->scratch, c->scratch_cap, m * ops->jac_bytes, err))) return rc;
-            if ((rc = grow(c->wtab, c->wtab_cap, m * ptau::WINDOW_ENTRIES * ops->wtab_entry_bytes, err))) return rc;
+            if ((rc = grow(scratch, scratch_cap, m * ops->jac_bytes, err))) return rc;
+            if ((rc = grow(wtab, wtab_cap, m * ptau::WINDOW_ENTRIES * ops->wtab_entry_bytes, err))) return rc;
             if (ops->subgroup_via_glv && use_endo_subgroup())   // [a]P + [b]phi(P) == O, |a|, |b| ~ sqrt(r): half the doublings, exact
-                ops->window_scalar_mul(c->stream, d_in + off * isz, cin, c->scratch, c->wtab, m,
+                ops->window_scalar_mul(st, d_in + off * isz, cin, scratch, wtab, m,
                                        ptau::ScalarSource{ptau::SCALAR_SUBGROUP_ENDO, nullptr, 0, 0, 0}, 0, /*use_glv=*/1, d_err);
             else
-                ops->window_scalar_mul(c->stream, d_in + off * isz, cin, c->scratch, c->wtab, m,
-                                       ptau::ScalarSource{ptau::SCALAR_FIXED, c->d_table, 0, 0, 0}, 0, /*use_glv=*/0, d_err);
-            if (via_psi) ops->psi_check(c->stream, d_in + off * isz, cin, c->scratch, m, d_err);
-            else ops->expect_infinity(c->stream, c->scratch, m, d_err);
+                ops->window_scalar_mul(st, d_in + off * isz, cin, scratch, wtab, m,
+                                       ptau::ScalarSource{ptau::SCALAR_FIXED, d_table, 0, 0, 0}, 0, /*use_glv=*/0, d_err);
+            if (via_psi) ops->psi_check(st, d_in + off * isz, cin, scratch, m, d_err);
+            else ops->expect_infinity(st, scratch, m, d_err);
         }
     }
-    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    if (!side) HIP_TRY(hipEventRecord(c->ev[1], st));
     return PTAU_OK;
 }
 

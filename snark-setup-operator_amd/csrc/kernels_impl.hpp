@@ -958,8 +958,12 @@ struct MsmPlan {
 // also valid (longer) coefficients of the random linear combination, and weighs a bucket with the cost of its test
 // (bucket_test_cost, in mixed additions).  Both sums of power_pairs are tested: A holds points 0 .. n-2, B points 1 .. n-1,
 // each placed by an independent rho.
+constexpr uint32_t MSM_RUN = 64, MSM_RUN_MAX = 128;   // entries per accumulate thread: the host picks the length of a launch in this range (capi.hip)
 struct MsmPlanEx : MsmPlan { int bits; };
-inline MsmPlanEx msm_plan(uint64_t m, int scalar_bits, int force_c = 0, int bucket_test_cost = 0) {
+// resident_runs (fused plans): accumulate threads resident on the device at once.  A bucket's partial sums are added up by
+// ONE thread of the combine pass (a full addition each, ~3.6 mixed additions of time), so few large buckets mean a long
+// latency-bound combine: that latency, times the lanes it leaves idle, joins the cost.
+inline MsmPlanEx msm_plan(uint64_t m, int scalar_bits, int force_c = 0, int bucket_test_cost = 0, uint64_t resident_runs = 0) {
     MsmPlanEx best{};
     double best_cost = -1;
     bool best_balanced = false;
@@ -977,7 +981,15 @@ inline MsmPlanEx msm_plan(uint64_t m, int scalar_bits, int force_c = 0, int buck
             const int top_bits = scalar_bits + 1 - (W - 1) * c;
             balanced = top_bits >= c - 2;
         }
-        const double cost = (double)W * ((double)m + (3.0 + bucket_test_cost) * (double)(1u << (c - 1)));
+        double cost = (double)W * ((double)m + (3.0 + bucket_test_cost) * (double)(1u << (c - 1)));
+        if (bucket_test_cost > 0 && resident_runs) {
+            const double total = (double)W * (double)m, R = (double)resident_runs;
+            const double k = total > R * MSM_RUN_MAX ? (double)(uint64_t)((total + R * MSM_RUN_MAX - 1) / (R * MSM_RUN_MAX)) : 1.0;
+            double L = total / (k * R);
+            L = L < MSM_RUN ? MSM_RUN : (L > MSM_RUN_MAX ? MSM_RUN_MAX : L);
+            const double parts = (double)m / (double)(1u << (c - 1)) / L + 1.0;
+            cost += parts * 3.6 * R;
+        }
         if (best_cost < 0 || (balanced && !best_balanced) || (balanced == best_balanced && cost < best_cost)) {
             best.c = c;
             best.W = W;
@@ -1072,11 +1084,12 @@ msm_scatter_kernel(const uint32_t *__restrict__ dig, uint32_t *__restrict__ curs
 }
 
 // Bucket sums in two steps so that one crowded bucket (a skewed scalar distribution, a short top window) cannot
-// serialise the pass: bucket b is cut into ceil(count_b / MSM_RUN) runs of at most MSM_RUN sorted entries;
-//   msm_accumulate : one thread per RUN — finds its bucket by bisection of the run offsets, adds +-P over its entries
+// serialise the pass and every thread has the same amount of work: the sorted entries are cut into runs of run_len
+// consecutive entries, whatever buckets they belong to;
+//   msm_accumulate : one thread per RUN — finds the bucket of its first entry by bisection of the offsets, adds +-P over its
+//                    entries, writing a partial sum whenever a bucket ends inside the run
 //                    (shift = 1 adds P_{i+1} instead of P_i: the shifted sum of power_pairs);
-//   msm_combine    : one thread per bucket — sums the bucket's run partials (one or two for a balanced window).
-constexpr uint32_t MSM_RUN = 64;
+//   msm_combine    : one thread per bucket — sums the bucket's partials (three or four at 2^20 points).
 
 // Affine point `idx` of an array written in the STANDARD (single-lane) layout — Affine<Fp2> = x.c0 x.c1 y.c0 y.c1 inf —
 // as the group's own Affine (lane-pair groups pick their coefficient).
@@ -1118,21 +1131,32 @@ PTAU_HD typename G::A load_affine_std(const typename G::A *aff, uint64_t idx) {
     }
 }
 
+// Partial-sum slots of bucket b under runs of run_len sorted entries ALIGNED TO THE ENTRY INDEX (run r = entries
+// [r run_len, (r + 1) run_len) whatever bucket they fall in): the runs floor(o_b / L) .. floor((o_{b+1} - 1) / L) touch it.
+PTAU_HD uint32_t msm_bucket_parts(uint32_t off, uint32_t cnt, uint32_t run_len) {
+    return cnt ? (off + cnt - 1) / run_len - off / run_len + 1 : 0;
+}
+
+// One run: run_len consecutive sorted entries, cut at bucket boundaries — every thread does the same number of additions
+// (the host sizes run_len so that the runs of a launch fill the resident lanes a whole number of times), and a bucket's
+// partial sums land in the contiguous slots run_offsets[b] ... (msm_combine adds them up).
 template <class G>
 PTAU_HD void msm_accumulate_thread(const typename G::A *aff, const uint32_t *sorted, const uint32_t *offsets,
                                    const uint32_t *run_offsets, typename G::J *partials, uint32_t shift,
-                                   uint32_t total_buckets, uint32_t v) {
+                                   uint32_t total_buckets, uint32_t v, uint32_t run_len = MSM_RUN) {
     using J = typename G::J;
     using F = typename G::F;
-    uint32_t lo = 0, hi = total_buckets;   // largest b with run_offsets[b] <= v  (run_offsets[total_buckets] > v)
+    const uint32_t total = offsets[total_buckets];
+    const uint64_t e0w = (uint64_t)v * run_len;
+    if (e0w >= total) return;
+    const uint32_t e0 = (uint32_t)e0w, e1 = e0w + run_len < total ? e0 + run_len : total;
+    uint32_t lo = 0, hi = total_buckets;   // largest b with offsets[b] <= e0: the (non-empty) bucket holding entry e0
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
-        if (run_offsets[mid] <= v) lo = mid; else hi = mid;
+        if (offsets[mid] <= e0) lo = mid; else hi = mid;
     }
-    const uint32_t b = lo;
-    const uint32_t e0 = offsets[b] + (v - run_offsets[b]) * MSM_RUN;
-    const uint32_t bend = offsets[b + 1];
-    const uint32_t e1 = e0 + MSM_RUN < bend ? e0 + MSM_RUN : bend;
+    uint32_t b = lo, bend = offsets[b + 1];
+    auto slot = [&](uint32_t bb) { return run_offsets[bb] + (v - offsets[bb] / run_len); };
     if constexpr (G::LAZY_LOOP && F::DEG == 2) {
         // Fq2 over a lane pair: the run is summed in the carry-free field (fpz.hpp), every point converted on the way in (one
         // base product per coordinate and lane against the ~40 % the additions save; for the prime-field groups the two
@@ -1142,6 +1166,11 @@ PTAU_HD void msm_accumulate_thread(const typename G::A *aff, const uint32_t *sor
         using Acc = typename L::Acc;
         Acc acc = Acc::infinity();
         for (uint32_t e = e0; e < e1; e++) {
+            if (e == bend) {   // the next bucket starts here
+                store_jac<G>(partials, slot(b), J{L::from_lazy(acc.X), L::from_lazy(acc.Y), L::from_lazy(acc.Zc)});
+                acc = Acc::infinity();
+                do { b++; bend = offsets[b + 1]; } while (bend <= e);
+            }
             const uint32_t s = sorted[e];
             const typename G::A q = load_affine_std<G>(aff, (uint64_t)(s & 0x7fffffffu) + shift);
             if (q.inf) continue;
@@ -1150,26 +1179,31 @@ PTAU_HD void msm_accumulate_thread(const typename G::A *aff, const uint32_t *sor
             if (s >> 31) ys = K::neg(y);
             acc = Acc::add_mixed(acc, x, ys);
         }
-        store_jac<G>(partials, v, J{L::from_lazy(acc.X), L::from_lazy(acc.Y), L::from_lazy(acc.Zc)});
+        store_jac<G>(partials, slot(b), J{L::from_lazy(acc.X), L::from_lazy(acc.Y), L::from_lazy(acc.Zc)});
         return;
     }
     J acc = J::infinity();
     for (uint32_t e = e0; e < e1; e++) {
+        if (e == bend) {
+            store_jac<G>(partials, slot(b), acc);
+            acc = J::infinity();
+            do { b++; bend = offsets[b + 1]; } while (bend <= e);
+        }
         const uint32_t s = sorted[e];
         typename G::A q = load_affine_std<G>(aff, (uint64_t)(s & 0x7fffffffu) + shift);
         if (s >> 31) q.y = F::neg(q.y);
         acc = J::add_mixed(acc, q);
     }
-    store_jac<G>(partials, v, acc);
+    store_jac<G>(partials, slot(b), acc);
 }
 template <class G>
 __global__ void __launch_bounds__(256, G::MIN_WAVES)
 msm_accumulate_kernel(const typename G::A *__restrict__ aff, const uint32_t *__restrict__ sorted,
                       const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ run_offsets,
-                      typename G::J *__restrict__ partials, uint32_t shift, uint32_t total_buckets) {
+                      typename G::J *__restrict__ partials, uint32_t shift, uint32_t total_buckets, uint32_t run_len) {
     const uint64_t v = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G::LPP;
-    if (v >= run_offsets[total_buckets]) return;   // the grid is sized for the worst case, the run count lives on the device
-    msm_accumulate_thread<G>(aff, sorted, offsets, run_offsets, partials, shift, total_buckets, (uint32_t)v);
+    if (v * run_len >= offsets[total_buckets]) return;   // the grid is sized for the worst case, the entry count lives on the device
+    msm_accumulate_thread<G>(aff, sorted, offsets, run_offsets, partials, shift, total_buckets, (uint32_t)v, run_len);
 }
 
 template <class G>
@@ -1643,7 +1677,9 @@ struct GroupOps {
     void (*msm_prepare)(hipStream_t, const uint8_t *in, int cin, void *aff, uint32_t *dig, uint32_t *counts, uint64_t n_points,
                         uint64_t n_scalars, ScalarSource src, MsmPlan pl, int *err);
     void (*msm_accumulate)(hipStream_t, const void *aff, const uint32_t *sorted, const uint32_t *offsets,
-                           const uint32_t *run_offsets, void *partials, uint32_t shift, uint32_t total_buckets, uint64_t max_runs);
+                           const uint32_t *run_offsets, void *partials, uint32_t shift, uint32_t total_buckets, uint64_t max_runs,
+                           uint32_t run_len);
+    int msm_lanes_per_run;   // threads the accumulate pass spends on one run (2 where the lane-pair twin serves it)
     void (*msm_combine)(hipStream_t, const void *partials, const uint32_t *run_offsets, void *buckets, uint64_t total_buckets);
     void (*msm_bucket_reduce)(hipStream_t, const void *buckets, void *parts, MsmPlan pl, uint64_t total);
     void (*reduce_rows)(hipStream_t, const void *in, void *out, uint32_t rows, uint32_t cols, uint32_t T);
@@ -1776,17 +1812,18 @@ struct Launch {
                            n_points, n_scalars, src, pl, err);
     }
     static void msm_accumulate(hipStream_t s, const void *aff, const uint32_t *sorted, const uint32_t *offsets,
-                               const uint32_t *run_offsets, void *partials, uint32_t shift, uint32_t total_buckets, uint64_t max_runs) {
+                               const uint32_t *run_offsets, void *partials, uint32_t shift, uint32_t total_buckets, uint64_t max_runs,
+                               uint32_t run_len) {
         if constexpr (!std::is_void_v<GL>) {
             static_assert(sizeof(typename G::A) == (2 * G::F::DEG * G::Fq::N + 1) * 4 || G::Fq::LB != 29, "standard affine layout");
             if (lane_pair_enabled()) {   // two threads per run; affine input and Jacobian partials in G's layouts
                 hipLaunchKernelGGL(msm_accumulate_kernel<GL>, grid(max_runs * 2), dim3(256), 0, s, (const typename GL::A *)aff,
-                                   sorted, offsets, run_offsets, (typename GL::J *)partials, shift, total_buckets);
+                                   sorted, offsets, run_offsets, (typename GL::J *)partials, shift, total_buckets, run_len);
                 return;
             }
         }
         hipLaunchKernelGGL(msm_accumulate_kernel<G>, grid(max_runs), dim3(256), 0, s, (const typename G::A *)aff, sorted,
-                           offsets, run_offsets, (typename G::J *)partials, shift, total_buckets);
+                           offsets, run_offsets, (typename G::J *)partials, shift, total_buckets, run_len);
     }
     static void msm_combine(hipStream_t s, const void *partials, const uint32_t *run_offsets, void *buckets, uint64_t total_buckets) {
         hipLaunchKernelGGL(msm_combine_kernel<G>, grid(total_buckets), dim3(256), 0, s, (const typename G::J *)partials,
@@ -1871,6 +1908,8 @@ struct Launch {
         o.affine_bytes = sizeof(typename G::A);
         o.msm_prepare = msm_prepare;
         o.msm_accumulate = msm_accumulate;
+        o.msm_lanes_per_run = 1;
+        if constexpr (!std::is_void_v<GL>) o.msm_lanes_per_run = GL::LPP;
         o.msm_combine = msm_combine;
         o.msm_bucket_reduce = msm_bucket_reduce;
         o.reduce_rows = reduce_rows;

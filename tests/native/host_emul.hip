@@ -155,18 +155,20 @@ static int run(const std::string &op, uint64_t n, uint64_t start, int cin, int c
         std::vector<uint32_t> dig(pl.W * std::max<uint64_t>(n, 1)), sorted(dig.size()), counts(wb, 0), offsets(wb + 1), run_offsets(wb + 1);
         ScalarSource src{SCALAR_ARRAY, k32.data(), 0, 0, 0};
         for (uint64_t i = 0; i < npts; i++) bad |= msm_prepare_thread<G>(in.data(), 0, aff.data(), dig.data(), counts.data(), npts, n, i, src, pl);
+        // a short run length so that small test inputs still cross bucket boundaries inside a run (PTAU_MSM_RUN as in capi.hip)
+        const uint32_t run_len = getenv("PTAU_MSM_RUN") ? (uint32_t)atoi(getenv("PTAU_MSM_RUN")) : 5u;
         uint32_t run = 0, rrun = 0;
         for (uint64_t j = 0; j < wb; j++) {
             offsets[j] = run; run_offsets[j] = rrun;
-            run += counts[j]; rrun += (counts[j] + MSM_RUN - 1) / MSM_RUN;
+            rrun += msm_bucket_parts(run, counts[j], run_len); run += counts[j];
             counts[j] = offsets[j];
         }
         offsets[wb] = run; run_offsets[wb] = rrun;
         for (uint64_t i = 0; i < n; i++) msm_scatter_thread(dig.data(), counts.data(), sorted.data(), n, i, pl);
         std::vector<J> buckets(nsum * wb), parts(nsum * wb), runs(rrun + 1);
         for (int sidx = 0; sidx < nsum; sidx++) {
-            for (uint32_t v = 0; v < rrun; v++)
-                msm_accumulate_thread<G>(aff.data(), sorted.data(), offsets.data(), run_offsets.data(), runs.data(), sidx, (uint32_t)wb, v);
+            for (uint32_t v = 0; (uint64_t)v * run_len < run; v++)
+                msm_accumulate_thread<G>(aff.data(), sorted.data(), offsets.data(), run_offsets.data(), runs.data(), sidx, (uint32_t)wb, v, run_len);
             for (uint64_t t = 0; t < wb; t++) msm_combine_thread<G>(runs.data(), run_offsets.data(), buckets.data() + sidx * wb, t);
         }
         const uint32_t rows = nsum * pl.W;
