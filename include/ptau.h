@@ -52,15 +52,20 @@ enum { PTAU_CHECK_NO = 0, PTAU_CHECK_ONLY_NON_ZERO = 1, PTAU_CHECK_ONLY_IN_GROUP
 enum { PTAU_SUBGROUP_AUTO = 0, PTAU_SUBGROUP_DIRECT = 1, PTAU_SUBGROUP_BATCHED = 2, PTAU_SUBGROUP_NO = 3 };
 /* setup_utils::BatchExpMode — src/bin/contribute.rs:134-139.  arkworks' batch_exp returns [k]P for ANY curve point, so:
  *   DIRECT                 : plain signed-window multiplication, exact on the whole curve;
- *   AUTO / BATCH_INVERSION : the same, EXCEPT when prime-order-subgroup membership of every input element was established
- *                            in the same call (check_input >= PTAU_CHECK_ONLY_IN_GROUP): then the endomorphism-accelerated
- *                            multiplication runs (GLV on BLS12-377 G1 / BW6-761, GLS on BLS12-377 G2) — equal to [k]P on the
- *                            subgroup, ~1.4x faster.  Where that membership test is much cheaper than the saving (BLS12-377
- *                            G2: 64 doublings against 188) Auto runs it by itself and takes the endomorphism path only when
- *                            every element passed — the bytes are the plain path's either way;
+ *   AUTO / BATCH_INVERSION : the same bytes, faster where the library can establish that every input element lies in the
+ *                            prime-order subgroup — then the endomorphism-accelerated multiplication runs (GLV on BLS12-377
+ *                            G1 / BW6-761, GLS on BLS12-377 G2 and the MNT twists), equal to [k]P on the subgroup, ~1.4x
+ *                            faster.  Membership is established (a) by check_input >= PTAU_CHECK_ONLY_IN_GROUP in the same
+ *                            call, or (b) by a PROBE the library runs by itself: on vectors of more than 2^12 elements the
+ *                            batched membership test (random bucket sums, each tested exactly; a vector with an element
+ *                            outside the subgroup passes with probability < 2^-128 — setup-utils' SubgroupCheckMode::Batched,
+ *                            SECURITY_PARAM = 128), whose bucket tests run beside the endomorphism kernel; on short BLS12-377
+ *                            G2 vectors the exact test.  When the probe fails, or the input is not even valid points, the
+ *                            plain path runs (and reports bad points as it always did): the bytes are the plain path's
+ *                            either way;
  *   | PTAU_BATCH_EXP_INPUT_IN_SUBGROUP : the CALLER asserts membership (the challenge came out of a verifier that ran the
  *                            subgroup checks, which is what the coordinator hands a contributor): the endomorphism path runs
- *                            without a membership pass.  On an element outside the subgroup the result would differ from
+ *                            without a probe.  On an element outside the subgroup the result would differ from
  *                            the reference's — never set it for data of unknown origin. */
 enum { PTAU_BATCH_EXP_AUTO = 0, PTAU_BATCH_EXP_DIRECT = 1, PTAU_BATCH_EXP_BATCH_INVERSION = 2, PTAU_BATCH_EXP_INPUT_IN_SUBGROUP = 0x100 };
 

@@ -18,6 +18,10 @@
 #include <cstring>
 #include <array>
 #include <atomic>
+#include <chrono>
+#include <thread>
+#include <deque>
+#include <condition_variable>
 #include <future>
 #include <memory>
 #include <mutex>
@@ -78,6 +82,21 @@ const ptau::PairingOps *get_pairing_ops(int curve) {
         if (e_ != hipSuccess)                                                                      \
             return err.fail(PTAU_E_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_));         \
     } while (0)
+
+// PTAU_TRACE=1: wall-clock marks of the file-level calls on stderr (where the host time of a call goes)
+struct Trace {
+    const char *what;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    static bool on() {
+        static const bool v = [] { const char *e = getenv("PTAU_TRACE"); return e && e[0] == '1'; }();
+        return v;
+    }
+    void mark(const char *label) const {
+        if (!on()) return;
+        fprintf(stderr, "[ptau trace] %s: %-34s %8.1f ms\n", what, label,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
 
 constexpr int MAX_DEVICES = 16;
 constexpr uint64_t MAX_LAUNCH_POINTS = 1ull << 20;   // points per kernel launch (scratch sizing)
@@ -981,11 +1000,70 @@ struct MappedFile {
     int fd = -1;
     std::future<void> populate;   // background page population / registration of an output mapping
     bool registered = false;
-    ~MappedFile() {
+    // The mappings of a finished call are taken apart on a background thread: unregistering and unmapping 750 MB - 1.1 GB of
+    // pinned file pages costs 45-50 ms, which nobody has to wait for once the output is synced (Reaper below).  A call that
+    // fails, or PTAU_TRACE=1, releases in place.
+    ~MappedFile() { release(); }
+    void release() {
         if (populate.valid()) populate.wait();
         if (registered) (void)hipHostUnregister(p);
         if (p != MAP_FAILED) munmap(p, len);
         if (fd >= 0) close(fd);
+        registered = false;
+        p = MAP_FAILED;
+        fd = -1;
+    }
+    struct Reaper {
+        struct Item { void *p; size_t len; int fd; bool registered; int device; };
+        std::mutex mu;
+        std::condition_variable cv;
+        std::deque<Item> q;
+        std::thread th;
+        bool stop = false;
+        void push(const Item &it) {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!th.joinable()) th = std::thread([this] { run(); });
+            q.push_back(it);
+            cv.notify_one();
+        }
+        void run() {
+            for (;;) {
+                Item it;
+                bool exiting;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [this] { return stop || !q.empty(); });
+                    if (q.empty()) return;
+                    it = q.front();
+                    q.pop_front();
+                    exiting = stop;
+                }
+                // at process exit the HIP runtime may already be gone: the OS takes the pins back with the mapping
+                if (it.registered && !exiting && hipSetDevice(it.device) == hipSuccess) (void)hipHostUnregister(it.p);
+                munmap(it.p, it.len);
+                if (it.fd >= 0) close(it.fd);
+            }
+        }
+        ~Reaper() {
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                stop = true;
+            }
+            cv.notify_all();
+            if (th.joinable()) th.join();
+        }
+    };
+    static Reaper &reaper() {
+        static Reaper r;
+        return r;
+    }
+    void release_async(int device) {
+        if (populate.valid()) populate.wait();
+        if (p != MAP_FAILED) reaper().push({p, len, fd, registered, device});
+        else if (fd >= 0) close(fd);
+        registered = false;
+        p = MAP_FAILED;
+        fd = -1;
     }
     static bool want_register() {
         static const bool w = [] {
@@ -1283,7 +1361,10 @@ int ptau_contribute_file(const ptau_params *p, const char *challenge_path, const
     memcpy(out + sz.contribution_size - sz.public_key_size, public_key, public_key_len);
     ptau_blake2b512(out, resp.len, digest);
     if (msync(resp.p, resp.len, MS_SYNC)) return err.fail(PTAU_E_IO, "msync failed: %s", strerror(errno));
-    return write_small_file(response_hash_path, digest, 64, err);
+    rc = write_small_file(response_hash_path, digest, 64, err);
+    resp.release_async(device);
+    ch.release_async(device);
+    return rc;
 }
 
 int ptau_contribute_file_seeded(const ptau_params *p, const char *challenge_path, const char *challenge_hash_path,
@@ -1330,7 +1411,10 @@ int ptau_contribute_file_seeded(const ptau_params *p, const char *challenge_path
     memcpy(out + sz.contribution_size - sz.public_key_size, pk.data(), pk.size());
     ptau_blake2b512(out, resp.len, digest);
     if (msync(resp.p, resp.len, MS_SYNC)) return err.fail(PTAU_E_IO, "msync failed: %s", strerror(errno));
-    return write_small_file(response_hash_path, digest, 64, err);
+    rc = write_small_file(response_hash_path, digest, 64, err);
+    resp.release_async(device);
+    ch.release_async(device);
+    return rc;
 }
 
 int ptau_decompress(int curve, int group, const uint8_t *in, uint8_t *out, uint64_t n, int check_output, int device,
@@ -1606,7 +1690,9 @@ int verify_chunk_impl(const ptau_params *p, const uint8_t *challenge, size_t cha
     const GroupOps *g1 = get_ops(p->curve, 1), *g2 = get_ops(p->curve, 2);
     DeviceCtx *c;
     if ((rc = ensure_ctx(device, c, err))) return rc;
+    Trace tr{"  verify_chunk"};
     std::unique_lock<std::mutex> lk(c->mu);   // held for the device section only: pairings and digests below run unlocked
+    tr.mark("device lock taken");
     HIP_TRY(hipSetDevice(device));
     c->timing = ptau_timing{};
     c->pending.bytes = 0;   // a copy left pending by a call that failed must never land
@@ -1660,6 +1746,7 @@ int verify_chunk_impl(const ptau_params *p, const uint8_t *challenge, size_t cha
     po += g2->uncomp;
     nc_ready.store((size_t)(po - new_challenge), std::memory_order_release);
     lk.unlock();   // another lane may use the device while this one finishes its host tail
+    tr.mark("device section done");
     // ---- host tail: every same-ratio check of this verification, one host thread each ----
     std::vector<RatioJob> ratio_jobs, pok_jobs;
     if (ratio_check) {
@@ -1693,6 +1780,7 @@ int verify_chunk_impl(const ptau_params *p, const uint8_t *challenge, size_t cha
     } ratio_join{fut_ratio};
     std::vector<uint8_t> pok_scratch, g2_s_own;
     const bool chain_ok = fut_chain.get();
+    tr.mark("BLAKE2b(challenge) done");
     if (verify_pok) {
         if (!g2_s) {
             g2_s_own.resize(3 * (size_t)g2->uncomp);
@@ -1704,6 +1792,7 @@ int verify_chunk_impl(const ptau_params *p, const uint8_t *challenge, size_t cha
         if ((rc = run_ratio_jobs(p->curve, pok_jobs, err, device))) return rc;
     }
     if ((rc = fut_ratio.get())) return err.fail(rc, "%s", ratio_msg);
+    tr.mark("pairing checks done");
     {   // how many pairing checks this call ran: ratio_checks == 0 under ratio_check means "not performed" (ptau.h)
         std::lock_guard<std::mutex> tl(c->mu);
         c->timing.ratio_checks = (uint32_t)ratio_jobs.size();
@@ -1714,7 +1803,9 @@ int verify_chunk_impl(const ptau_params *p, const uint8_t *challenge, size_t cha
     if (!chain_ok)
         return err.fail(PTAU_E_HASH_CHAIN, "response does not start with the hash of the challenge it claims to extend");
     joiner.ok = true;
+    tr.mark("BLAKE2b(response) done");
     if (fut_nc.valid()) fut_nc.wait();
+    tr.mark("BLAKE2b(new challenge) done");
     return PTAU_OK;
 }
 }  // namespace
@@ -1744,6 +1835,7 @@ int ptau_transform_pok_and_correctness_file(const ptau_params *p, const char *ch
         return err.fail(PTAU_E_ARG, "null pointer argument");
     ptau_sizes sz;
     ptau_params_sizes(p, &sz);
+    Trace tr{"transform_pok_and_correctness"};
     MappedFile ch, resp, nc;
     if ((rc = ch.open_ro(challenge_path, err))) return rc;
     if ((rc = resp.open_ro(response_path, err, /*pin=*/true, device))) return rc;
@@ -1752,9 +1844,12 @@ int ptau_transform_pok_and_correctness_file(const ptau_params *p, const char *ch
                         resp.len, (unsigned long long)sz.accumulator_size, (unsigned long long)sz.contribution_size);
     if ((rc = nc.create_new(new_challenge_path, sz.accumulator_size, err, device))) return rc;
     VerifyDigests dg;
+    tr.mark("files mapped");
     resp.wait_pinned();
+    tr.mark("response pinned");
     rc = verify_chunk_impl(p, (const uint8_t *)ch.p, ch.len, (const uint8_t *)resp.p, resp.len, (uint8_t *)nc.p, nc.len, check_input,
                            check_output, subgroup_check_mode, ratio_check, /*verify_pok=*/1, g2_s, tau_g2_check, device, &dg, errbuf, err_len);
+    tr.mark("verify_chunk_impl done");
     // the reference writes challenge.hash and response.hash before it verifies: keep them on the failure paths that got that far
     if (rc == PTAU_OK || rc == PTAU_E_HASH_CHAIN || rc == PTAU_E_INVALID_RATIO || rc == PTAU_E_NOT_IN_SUBGROUP ||
         rc == PTAU_E_POINT_AT_INFINITY || rc == PTAU_E_POINT) {
@@ -1764,7 +1859,20 @@ int ptau_transform_pok_and_correctness_file(const ptau_params *p, const char *ch
     }
     if (rc) return rc;
     if (msync(nc.p, nc.len, MS_SYNC)) return err.fail(PTAU_E_IO, "msync failed: %s", strerror(errno));
-    return write_small_file(new_challenge_hash_path, dg.new_challenge, 64, err);
+    tr.mark("msync done");
+    rc = write_small_file(new_challenge_hash_path, dg.new_challenge, 64, err);
+    if (Trace::on() && getenv("PTAU_SYNC_UNMAP")) {   // what taking the mappings apart costs
+        nc.release();
+        tr.mark("new challenge unmapped");
+        resp.release();
+        ch.release();
+        tr.mark("inputs unmapped");
+    }
+    nc.release_async(device);
+    resp.release_async(device);
+    ch.release_async(device);
+    tr.mark("returning");
+    return rc;
 }
 
 int ptau_msm(int curve, int group, const uint8_t *in, int compressed_in, uint64_t n, const uint64_t *scalars, uint8_t *out,

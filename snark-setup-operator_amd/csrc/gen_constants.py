@@ -170,7 +170,7 @@ def field(name, p, cubic_nr=None, sqrt_tables=False, lb=32, n_limbs=None):
         #   SQRT_ZLOW[k]     = low Montgomery limb of zeta^k, zeta = (g^2)^(2^(E-W)) of order 2^W (lookup key)
         #   SQRT_GNEG[j][k]  = g^(-k 2^(W j)), Montgomery: strips window j from the residue and builds g^(-d)
         E = S - 1
-        W = min(6, E) if E > 0 else 0
+        W = min(8, E) if E > 0 else 0      # 8-bit windows: S^2 / 16 squarings in the torsion stage (6-bit: S^2 / 12), 256-entry lookup
         L = (E + W - 1) // W if W else 0
         g = pow(z, T, p)
         s.append("  static constexpr int SQRT_W = %d;" % W)
