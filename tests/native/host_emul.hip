@@ -9,6 +9,8 @@
 //        fieldz: the same input; arithmetic of the carry-free twin field (fpz.hpp), see the op
 //        gls2split: MNT twists only.  <n> = 0, <start> = the number of scalars; stdin = scalars x 24 u32 words; stdout per scalar: k0 (12 words) | k1 (12 words) of the
 //               Euclidean split k = k0 + k1 |t - 1| K1's GLS loop consumes (k1_lazy_a.hpp)
+//        msmplan: no input; <n> = points, <start> = bucket test cost (0 = the plain plan for 127-bit scalars), <cin> = resident runs
+//               in thousands; stdout = text "c W B bits"
 //        subgroup : stdin = n points; stdout = n bytes of error bits (0 = in the prime-order subgroup)
 //        msm  : stdin = n points (uncompressed) then n x Fr::N u32 scalar limbs; <start> = window bits c (0 = the
 //               library's own plan), <cout> = 1 adds the shifted sum (needs n + 1 points); stdout = 1 or 2 points
@@ -255,6 +257,11 @@ int main(int argc, char **argv) {
     int curve = atoi(argv[2]), group = atoi(argv[3]);
     uint64_t n = strtoull(argv[4], 0, 10), start = strtoull(argv[5], 0, 10);
     int cin = atoi(argv[6]), cout = atoi(argv[7]);
+    if (op == "msmplan") {
+        const MsmPlanEx pl = msm_plan(std::max<uint64_t>(n, 1), PRF_BITS, 0, (int)start, (uint64_t)cin * 1000);
+        printf("%d %d %u %d\n", pl.c, pl.W, pl.B, pl.bits);
+        return 0;
+    }
     switch (curve) {
     case 0: DISPATCH(BlsFqR29, BlsFr, BlsG1Cfg, BlsG2Cfg)
     case 1: DISPATCH(Bw6FqR29, Bw6Fr, Bw6G1Cfg, Bw6G2Cfg)

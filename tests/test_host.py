@@ -507,3 +507,29 @@ def test_only_context_creation_takes_a_process_wide_lock():
     # per-device state: the device mutex and the pairing mutex live in DeviceCtx
     ctx = src[src.index("struct DeviceCtx {"):src.index("DeviceCtx g_ctx[MAX_DEVICES];")]
     assert "std::mutex mu;" in ctx and "std::mutex pair_mu;" in ctx
+
+
+def test_membership_fused_msm_plan_meets_the_security_parameter():
+    """msm_plan with a bucket test cost (the batched subgroup check riding on the ratio check's MSM, and the probe of
+    BatchExpMode::Auto): every window is a round of setup-utils' batched check with false-accept probability <= 2^-(c-1)
+    (2^-(c-2) for the top window), so W (c - 1) - 1 >= 128 (SECURITY_PARAM) must hold for every size and cost, the
+    coefficients are exactly W c - 1 bits wide (full windows, no carry out of the top one) and fit the PRF; the plain plan
+    (cost 0) still serves 127-bit coefficients."""
+    exe = os.path.join(ROOT, "tests", "native", "host_emul")
+    if not os.path.exists(exe):
+        pytest.skip("host_emul not built")
+    def plan(n, cost, resident_k):
+        r = subprocess.run([exe, "msmplan", "0", "1", str(n), str(cost), str(resident_k), "0", "0", "-"], capture_output=True, stdin=subprocess.DEVNULL)
+        assert r.returncode == 0
+        return [int(v) for v in r.stdout.split()]
+    for n in (1, 2, 100, 4097, 1 << 13, 1 << 16, 1 << 18, (1 << 20) - 1, 1 << 20, 1 << 22):
+        c, W, B, bits = plan(n, 0, 0)
+        assert B == 1 << (c - 1) and W * c >= 127 + 1 and bits == 127
+        for cost in (1, 46, 93, 170, 300, 565):
+            for resident in (0, 65, 131):
+                c, W, B, bits = plan(n, cost, resident)
+                assert 3 <= c <= 16 and B == 1 << (c - 1)
+                assert W * (c - 1) - 1 >= 128, (n, cost, c, W)
+                assert bits == W * c - 1 and bits <= 200
+    # more expensive tests push the plan towards fewer, larger buckets
+    assert plan(1 << 20, 300, 131)[0] <= plan(1 << 20, 46, 131)[0]
