@@ -547,7 +547,6 @@ int run_msm_bucket_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, i
                                hipMemcpyHostToDevice, c->stream));
     }
     HIP_TRY(hipEventRecord(defer_tail ? c->tev[0] : c->ev[0], c->stream));
-    if (only && !cin) ops->on_curve(c->stream, d_in, n, d_err);   // bucket sums of points off the curve would mean nothing
     uint64_t li = 0;
     for (uint64_t off = 0; off < n || (n == 0 && li == 0); off += MSM_SLICE_POINTS, li++) {
         const uint64_t m = std::min(MSM_SLICE_POINTS, n - off);
@@ -558,7 +557,8 @@ int run_msm_bucket_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, i
         if (s2.mode == ptau::SCALAR_ARRAY) s2.ptr += off * ops->fr_limbs32;
         s2.index_base += off;
         HIP_TRY(hipMemsetAsync(counts, 0, wb * 4, c->stream));
-        ops->msm_prepare(c->stream, d_in + off * isz, cin, aff, dig, counts, m + (nsum - 1), m, s2, pl, d_err);
+        // (the probe's uncompressed input gets its on-curve test here: bucket sums of points off the curve would mean nothing)
+        ops->msm_prepare(c->stream, d_in + off * isz, only && !cin ? 2 : cin, aff, dig, counts, m + (nsum - 1), m, s2, pl, d_err);
         const uint32_t run_len = msm_run_length(c, ops, m, pl);
         hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, c->stream, counts, offsets, run_offsets, (uint32_t)wb, run_len);
         if (m) hipLaunchKernelGGL(ptau::msm_scatter_kernel<0>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, dig, counts, sorted, m, pl);

@@ -1011,6 +1011,20 @@ PTAU_HD uint32_t atomic_inc_u32(uint32_t *p) {
 #endif
 }
 
+// The MSM's affine array of a one-lane prime-field group with a carry-free twin (BLS12-377 G1) is kept IN that field's
+// Montgomery form — x | y as 14 limbs of 28 bits, then the flag word — so that the bucket accumulation runs the carry-free
+// mixed addition without converting every point it meets (msm_prepare converts once per point).
+template <class G>
+constexpr bool msm_aff_lazy() {
+    if constexpr (G::LAZY_LOOP) return G::F::DEG == 1 && G::LANE_MODE == LANES_ONE;
+    else return false;
+}
+template <class G>
+constexpr size_t msm_aff_bytes() {
+    if constexpr (msm_aff_lazy<G>()) return (2 * LazyOf<G>::N + 1) * sizeof(uint32_t);
+    else return sizeof(typename G::A);
+}
+
 // digit entry: 0 = nothing to add; else bit 31 = negative, low bits = magnitude in [1, 2^(c-1)]
 template <class G>
 PTAU_HD int msm_prepare_thread(const uint8_t *in, int compressed_in, typename G::A *aff, uint32_t *dig,
@@ -1020,10 +1034,20 @@ PTAU_HD int msm_prepare_thread(const uint8_t *in, int compressed_in, typename G:
     using F = typename G::F;
     constexpr int NL = Fr::N;
     typename G::A p;
-    int bad = read_point_any<G>(in, compressed_in, i, p);
+    const bool on_curve_too = compressed_in == 2;   // uncompressed input that nobody has looked at yet (the probe of Auto)
+    int bad = read_point_any<G>(in, on_curve_too ? 0 : compressed_in, i, p);
+    if (!bad && on_curve_too && !p.inf && !(F::sqr(p.y) == curve_rhs<F, typename G::J::CfgT>(p.x))) bad |= ERRBIT_NOT_ON_CURVE;
     if (bad) p.inf = true;
     if (p.inf) { p.x = F::zero(); p.y = F::zero(); }
-    aff[i] = p;
+    if constexpr (msm_aff_lazy<G>()) {
+        using L = LazyOf<G>;
+        uint32_t *w = reinterpret_cast<uint32_t *>(aff) + i * (2 * L::N + 1);
+        L::store(w, L::to_lazy(p.x));
+        L::store(w + L::N, L::to_lazy(p.y));
+        w[2 * L::N] = p.inf ? 1u : 0u;
+    } else {
+        aff[i] = p;
+    }
     if (i >= n_scalars) return bad;
     uint32_t k[NL];
     thread_scalar<Fr>(src, i, k);
@@ -1175,6 +1199,29 @@ PTAU_HD void msm_accumulate_thread(const typename G::A *aff, const uint32_t *sor
             const typename G::A q = load_affine_std<G>(aff, (uint64_t)(s & 0x7fffffffu) + shift);
             if (q.inf) continue;
             const auto x = L::to_lazy(q.x), y = L::to_lazy(q.y);
+            typename L::AY ys = y;
+            if (s >> 31) ys = K::neg(y);
+            acc = Acc::add_mixed(acc, x, ys);
+        }
+        store_jac<G>(partials, slot(b), J{L::from_lazy(acc.X), L::from_lazy(acc.Y), L::from_lazy(acc.Zc)});
+        return;
+    }
+    if constexpr (msm_aff_lazy<G>()) {
+        // one-lane prime field with a carry-free twin: the array already holds that field's form (msm_aff_lazy)
+        using L = LazyOf<G>;
+        using K = typename L::K;
+        using Acc = typename L::Acc;
+        Acc acc = Acc::infinity();
+        for (uint32_t e = e0; e < e1; e++) {
+            if (e == bend) {
+                store_jac<G>(partials, slot(b), J{L::from_lazy(acc.X), L::from_lazy(acc.Y), L::from_lazy(acc.Zc)});
+                acc = Acc::infinity();
+                do { b++; bend = offsets[b + 1]; } while (bend <= e);
+            }
+            const uint32_t s = sorted[e];
+            const uint32_t *w = reinterpret_cast<const uint32_t *>(aff) + ((uint64_t)(s & 0x7fffffffu) + shift) * (2 * L::N + 1);
+            if (w[2 * L::N]) continue;
+            const auto x = L::template load<typename L::C>(w), y = L::template load<typename L::C>(w + L::N);
             typename L::AY ys = y;
             if (s >> 31) ys = K::neg(y);
             acc = Acc::add_mixed(acc, x, ys);
@@ -1905,7 +1952,7 @@ struct Launch {
         o.window_scalar_mul = window_scalar_mul;
         o.on_curve = on_curve;
         o.reduce_sum = reduce_sum;
-        o.affine_bytes = sizeof(typename G::A);
+        o.affine_bytes = msm_aff_bytes<G>();
         o.msm_prepare = msm_prepare;
         o.msm_accumulate = msm_accumulate;
         o.msm_lanes_per_run = 1;

@@ -153,10 +153,11 @@ static int run(const std::string &op, uint64_t n, uint64_t start, int cin, int c
         if (n && fread(k32.data(), 4, k32.size(), stdin) != k32.size()) return 2;
         const MsmPlan pl = msm_plan(std::max<uint64_t>(n, 1), G::Fr::Params::BITS, (int)start);
         const uint64_t wb = (uint64_t)pl.W * pl.B;
-        std::vector<typename G::A> aff(npts);
+        std::vector<uint64_t> aff_store((npts * msm_aff_bytes<G>() + 7) / 8 + 1);   // the array's element is the group's own (msm_aff_bytes)
+        typename G::A *const aff_p = reinterpret_cast<typename G::A *>(aff_store.data());
         std::vector<uint32_t> dig(pl.W * std::max<uint64_t>(n, 1)), sorted(dig.size()), counts(wb, 0), offsets(wb + 1), run_offsets(wb + 1);
         ScalarSource src{SCALAR_ARRAY, k32.data(), 0, 0, 0};
-        for (uint64_t i = 0; i < npts; i++) bad |= msm_prepare_thread<G>(in.data(), 0, aff.data(), dig.data(), counts.data(), npts, n, i, src, pl);
+        for (uint64_t i = 0; i < npts; i++) bad |= msm_prepare_thread<G>(in.data(), 0, aff_p, dig.data(), counts.data(), npts, n, i, src, pl);
         // a short run length so that small test inputs still cross bucket boundaries inside a run (PTAU_MSM_RUN as in capi.hip)
         const uint32_t run_len = getenv("PTAU_MSM_RUN") ? (uint32_t)atoi(getenv("PTAU_MSM_RUN")) : 5u;
         uint32_t run = 0, rrun = 0;
@@ -170,7 +171,7 @@ static int run(const std::string &op, uint64_t n, uint64_t start, int cin, int c
         std::vector<J> buckets(nsum * wb), parts(nsum * wb), runs(rrun + 1);
         for (int sidx = 0; sidx < nsum; sidx++) {
             for (uint32_t v = 0; (uint64_t)v * run_len < run; v++)
-                msm_accumulate_thread<G>(aff.data(), sorted.data(), offsets.data(), run_offsets.data(), runs.data(), sidx, (uint32_t)wb, v, run_len);
+                msm_accumulate_thread<G>(aff_p, sorted.data(), offsets.data(), run_offsets.data(), runs.data(), sidx, (uint32_t)wb, v, run_len);
             for (uint64_t t = 0; t < wb; t++) msm_combine_thread<G>(runs.data(), run_offsets.data(), buckets.data() + sidx * wb, t);
         }
         const uint32_t rows = nsum * pl.W;
