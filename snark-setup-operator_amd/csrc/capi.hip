@@ -149,6 +149,16 @@ struct DeviceCtx {
     void *d_pair = nullptr;                   // packed checks | results | GT values
     size_t pair_cap = 0;
     size_t in_cap = 0, out_cap = 0;
+    // contribute: the NEXT vector's input is copied to the device (copy stream, second input buffer) while this vector's kernels run
+    void *d_in_alt = nullptr;
+    size_t in_alt_cap = 0;
+    int in_sel = 0;
+    hipEvent_t pev[2] = {};   // brackets of the prefetch copy
+    struct Prefetch {
+        const void *host = nullptr;
+        size_t bytes = 0;
+        void *dev = nullptr;
+    } prefetch;
     // side stream for the lone beta_g2 element of a chunk: its membership test is ONE thread's scalar multiplication
     // (~170 ms of latency on MNT4 G2, ~370 ms on MNT6 G2) and runs beside the vectors instead of after them
     hipStream_t side_stream = nullptr;
@@ -214,13 +224,13 @@ int ensure_ctx(int device, DeviceCtx *&c, const Err &err, bool side = false) {
     std::lock_guard<std::mutex> init_lk(g_init_mu);
     if (c->ready) return PTAU_OK;
     hipStream_t st[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t evs[12] = {};
+    hipEvent_t evs[14] = {};
     void *bufs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     const size_t buf_sz[5] = {sizeof(uint32_t) * (1 + ptau::SCALAR_TABLE_ENTRIES) * 24, 256, 4096, 16384, TB_SIZE};
     hipError_t e = hipSuccess;
     const char *what = "";
     for (int i = 0; i < 5 && e == hipSuccess; i++) { e = hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking); what = "hipStreamCreateWithFlags"; }
-    for (int i = 0; i < 12 && e == hipSuccess; i++) { e = hipEventCreate(&evs[i]); what = "hipEventCreate"; }
+    for (int i = 0; i < 14 && e == hipSuccess; i++) { e = hipEventCreate(&evs[i]); what = "hipEventCreate"; }
     for (int i = 0; i < 5 && e == hipSuccess; i++) { e = hipMalloc(&bufs[i], buf_sz[i]); what = "hipMalloc"; }
     if (e != hipSuccess) {
         for (auto s : st) if (s) (void)hipStreamDestroy(s);
@@ -237,6 +247,8 @@ int ensure_ctx(int device, DeviceCtx *&c, const Err &err, bool side = false) {
     c->cev[0] = evs[6];
     c->cev[1] = evs[7];
     for (int i = 0; i < 4; i++) c->tev[i] = evs[8 + i];
+    c->pev[0] = evs[12];
+    c->pev[1] = evs[13];
     c->t_buf = (uint8_t *)bufs[4];
     c->bk_table = (uint32_t *)(c->t_buf + TB_TABLE);
     c->d_table = (uint32_t *)bufs[0];
@@ -380,25 +392,52 @@ int run_apply_powers_dev(DeviceCtx *c, int curve, int group, const GroupOps *ops
 // the caller flushes after its last vector.
 int run_apply_powers_host(DeviceCtx *c, int curve, int group, const GroupOps *ops, const uint8_t *in, int cin, uint8_t *out, int cout, uint64_t n,
                           uint64_t start, const uint64_t *tau, const uint64_t *coeff, int check_input, int use_endo, const Err &err,
-                          bool defer_copy = false) {
+                          bool defer_copy = false, const uint8_t *next_in = nullptr, size_t next_bytes = 0) {
     const size_t isz = cin ? ops->comp : ops->uncomp, osz = cout ? ops->comp : ops->uncomp;
     if (!n) return PTAU_OK;
     int rc;
     void *&d_out = c->out_sel ? c->d_out_alt : c->d_out;
     size_t &d_out_cap = c->out_sel ? c->out_alt_cap : c->out_cap;
     c->out_sel ^= 1;
-    if ((rc = grow(c->d_in, c->in_cap, n * isz, err))) return rc;
     if ((rc = grow(d_out, d_out_cap, n * osz, err))) return rc;
     float ms = 0;
-    HIP_TRY(hipEventRecord(c->ev[3], c->stream));
-    HIP_TRY(hipMemcpyAsync(c->d_in, in, n * isz, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipEventRecord(c->ev[4], c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
+    void *d_in;
+    if (c->prefetch.host == in && c->prefetch.bytes == n * isz) {   // copied while the previous vector's kernels ran
+        d_in = c->prefetch.dev;
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->pev[1], 0));
+        HIP_TRY(hipEventSynchronize(c->pev[1]));
+        HIP_TRY(hipEventElapsedTime(&ms, c->pev[0], c->pev[1]));
+    } else {
+        void *&buf = c->in_sel ? c->d_in_alt : c->d_in;
+        size_t &cap = c->in_sel ? c->in_alt_cap : c->in_cap;
+        if ((rc = grow(buf, cap, n * isz, err))) return rc;
+        d_in = buf;
+        HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+        HIP_TRY(hipMemcpyAsync(d_in, in, n * isz, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipEventRecord(c->ev[4], c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
+    }
+    c->prefetch = DeviceCtx::Prefetch{};
+    c->in_sel ^= 1;
     c->timing.h2d_ms += ms;
-    if ((rc = run_apply_powers_dev(c, curve, group, ops, (const uint8_t *)c->d_in, cin, (uint8_t *)d_out, cout, n, start, tau, coeff,
-                                   check_input, use_endo, err)))
+    if (next_in && next_bytes) {   // the other input buffer is free: its last reader finished before this call
+        void *&nbuf = c->in_sel ? c->d_in_alt : c->d_in;
+        size_t &ncap = c->in_sel ? c->in_alt_cap : c->in_cap;
+        if ((rc = grow(nbuf, ncap, next_bytes, err))) return rc;
+        HIP_TRY(hipEventRecord(c->pev[0], c->copy_stream));
+        HIP_TRY(hipMemcpyAsync(nbuf, next_in, next_bytes, hipMemcpyHostToDevice, c->copy_stream));
+        HIP_TRY(hipEventRecord(c->pev[1], c->copy_stream));
+        c->prefetch.host = next_in;
+        c->prefetch.bytes = next_bytes;
+        c->prefetch.dev = nbuf;
+    }
+    if ((rc = run_apply_powers_dev(c, curve, group, ops, (const uint8_t *)d_in, cin, (uint8_t *)d_out, cout, n, start, tau, coeff,
+                                   check_input, use_endo, err))) {
+        if (c->prefetch.host) (void)hipStreamSynchronize(c->copy_stream);   // never leave a copy from the caller's buffer in flight
+        c->prefetch = DeviceCtx::Prefetch{};
         return rc;
+    }
     c->pending.src = d_out;
     c->pending.dst = out;
     c->pending.bytes = n * osz;
@@ -1309,11 +1348,17 @@ int ptau_phase1_computation(const ptau_params *p, const uint8_t *in, size_t in_l
         std::future<int> &f;
         ~SideJoin() { if (f.valid()) f.wait(); }
     } side_join{side};
-    if ((rc = run_apply_powers_host(c, p->curve, 1, g1, pi, 0, po, 1, n1, s, tau, nullptr, check_input, use_endo, err, /*defer_copy=*/true))) return rc;
+    c->prefetch = DeviceCtx::Prefetch{};
+    // every call names the NEXT vector's input: it is copied to the device while this vector's kernels run
+    const uint8_t *in_tau_g2 = pi + n1 * g1->uncomp, *in_alpha = in_tau_g2 + n2 * g2->uncomp, *in_beta = in_alpha + n2 * g1->uncomp;
+    if ((rc = run_apply_powers_host(c, p->curve, 1, g1, pi, 0, po, 1, n1, s, tau, nullptr, check_input, use_endo, err, /*defer_copy=*/true,
+                                    n2 ? in_tau_g2 : nullptr, n2 * g2->uncomp))) return rc;
     pi += n1 * g1->uncomp; po += n1 * g1->comp;
-    if ((rc = run_apply_powers_host(c, p->curve, 2, g2, pi, 0, po, 1, n2, s, tau, nullptr, check_input, use_endo, err, /*defer_copy=*/true))) return rc;
+    if ((rc = run_apply_powers_host(c, p->curve, 2, g2, pi, 0, po, 1, n2, s, tau, nullptr, check_input, use_endo, err, /*defer_copy=*/true,
+                                    in_alpha, n2 * g1->uncomp))) return rc;
     pi += n2 * g2->uncomp; po += n2 * g2->comp;
-    if ((rc = run_apply_powers_host(c, p->curve, 1, g1, pi, 0, po, 1, n2, s, tau, alpha, check_input, use_endo, err, /*defer_copy=*/true))) return rc;
+    if ((rc = run_apply_powers_host(c, p->curve, 1, g1, pi, 0, po, 1, n2, s, tau, alpha, check_input, use_endo, err, /*defer_copy=*/true,
+                                    in_beta, n2 * g1->uncomp))) return rc;
     pi += n2 * g1->uncomp; po += n2 * g1->comp;
     if ((rc = run_apply_powers_host(c, p->curve, 1, g1, pi, 0, po, 1, n2, s, tau, beta, check_input, use_endo, err, /*defer_copy=*/true))) return rc;
     pi += n2 * g1->uncomp; po += n2 * g1->comp;

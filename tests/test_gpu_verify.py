@@ -627,3 +627,29 @@ def test_auto_probe_batched_on_long_vectors(name, group, pkg, cref):
         assert got == exp, (name, group, pos)
         lo = max(0, min(pos - 1, n - 3))
         assert got[lo * csz:(lo + 3) * csz] == cref.apply_powers(name, group, bytes(bad[lo * usz:(lo + 3) * usz]), 3, 11 + lo, tau, coeff, False, True)
+    # input that is not even a vector of curve points: the speculative endomorphism launch is thrown away and the plain path
+    # reports what Direct reports
+    x, y = G.mul(G.gen, 5)
+    off_curve = serde.write_point(G, (x, G.F.add(y, G.F.one())), False)
+    non_canonical = b"\xff" * (usz - 1) + b"\x3f"
+    bad = bytearray(vec)
+    bad[777 * usz:778 * usz] = non_canonical
+    for mode in (pkg.BatchExpMode.Auto, pkg.BatchExpMode.Direct):
+        with pytest.raises(pkg.PtauError) as e:
+            pkg.phase1_cli.apply_powers(name, group, bytes(bad), n, 11, tau, coeff, False, True, batch_exp_mode=mode)
+        assert e.value.code == -3, (name, group, mode, e.value)
+    # an uncompressed (x, y) that is not on the curve is not looked at under CheckForCorrectness::No (deserialize_unchecked): the
+    # plain formulas run on it; Auto's probe sees it is no curve point and must end on the same plain path
+    bad[777 * usz:778 * usz] = off_curve
+    assert pkg.phase1_cli.apply_powers(name, group, bytes(bad), n, 11, tau, coeff, False, True, batch_exp_mode=pkg.BatchExpMode.Auto) == \
+        pkg.phase1_cli.apply_powers(name, group, bytes(bad), n, 11, tau, coeff, False, True, batch_exp_mode=pkg.BatchExpMode.Direct)
+    inf = bytearray(vec)
+    inf[5 * usz:6 * usz] = serde.write_point(G, None, False)
+    for mode in (pkg.BatchExpMode.Auto, pkg.BatchExpMode.Direct):
+        with pytest.raises(pkg.PtauError) as e:
+            pkg.phase1_cli.apply_powers(name, group, bytes(inf), n, 11, tau, coeff, False, True, check_input=pkg.CheckForCorrectness.OnlyNonZero,
+                                        batch_exp_mode=mode)
+        assert e.value.code == -4
+    # ... and an infinity element is a legal input when nobody asked for non-zero elements: same bytes on both paths
+    assert pkg.phase1_cli.apply_powers(name, group, bytes(inf), n, 11, tau, coeff, False, True, batch_exp_mode=pkg.BatchExpMode.Auto) == \
+        pkg.phase1_cli.apply_powers(name, group, bytes(inf), n, 11, tau, coeff, False, True, batch_exp_mode=pkg.BatchExpMode.Direct)

@@ -42,6 +42,29 @@ def run(lg):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def run_contribute(lg, asserted):
+    """Two contributions of chunk 0 (the second one is what `read` isolates): default flags, or membership asserted."""
+    import shutil
+    import tempfile
+    from bench import load_pkg
+    pkg = load_pkg()
+    n = 1 << lg
+    prm = pkg.Phase1Parameters.new_chunk("bls12_377", 0, 0, n, 0, lg, n)
+    d = tempfile.mkdtemp(prefix="ptau_ct_", dir="/dev/shm" if os.access("/dev/shm", os.W_OK) else None)
+    f = lambda s: os.path.join(d, s)
+    mode = int(pkg.BatchExpMode.Auto) | (pkg.phase1_cli.INPUT_IN_SUBGROUP if asserted else 0)
+    try:
+        pkg.new_challenge(f("c0"), f("c0.hash"), prm)
+        for k in range(2):
+            if k == 1:
+                time.sleep(1.5)
+            pkg.phase1_cli.contribute_seeded(f("c0"), f("c0.h%d" % k), f("r%d" % k), f("r%d.hash" % k), pkg.CheckForCorrectness.No, mode,
+                                             prm, b"bench verify seed".ljust(64, b"."), device=0)
+            print(k, pkg.phase1_cli.last_timing(0), flush=True)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def read(path):
     rows = []
     for fn in glob.glob(os.path.join(path, "**", "*kernel_trace.csv"), recursive=True):
@@ -88,5 +111,7 @@ def read(path):
 if __name__ == "__main__":
     if sys.argv[1] == "run":
         run(int(sys.argv[2]) if len(sys.argv) > 2 else 20)
+    elif sys.argv[1] in ("contribute", "contribute_asserted"):
+        run_contribute(int(sys.argv[2]) if len(sys.argv) > 2 else 20, sys.argv[1] == "contribute_asserted")
     else:
         read(sys.argv[2])
