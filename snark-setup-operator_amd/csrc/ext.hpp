@@ -4,9 +4,19 @@
 // BLS12-377, MNT4-753 (D = 2) and MNT6-753 (D = 3)); NR is a small signed integer so the
 // non-residue product is a short addition chain instead of a field multiplication.
 #pragma once
+#include <type_traits>
+
 #include "fpl.hpp"
 
 namespace ptau {
+
+// base fields that can tell "square / non-square" and produce the root of a or of NR a from one exponentiation (fp29.hpp)
+template <class F, class = void>
+struct HasSqrtOrNr : std::false_type {};
+template <class F>
+struct HasSqrtOrNr<F, std::void_t<decltype(F::HAS_SQRT_OR_NR)>> : std::bool_constant<F::HAS_SQRT_OR_NR> {};
+template <class F>
+constexpr bool has_sqrt_or_nr() { return HasSqrtOrNr<F>::value; }
 
 template <class F, int NR>
 struct Fp2 {
@@ -85,15 +95,31 @@ struct Fp2 {
         if (!F::sqrt(norm, alpha)) return false;
         F two_inv = F::from_canonical(F::Params::QP1H);   // (p+1)/2 = 1/2
         F delta = F::mul(F::add(a.c0, alpha), two_inv);
-        F x0, x0_inv;
-        if (!F::sqrt_ex(delta, x0, &x0_inv)) {
-            delta = F::mul(F::sub(a.c0, alpha), two_inv);
-            if (!F::sqrt_ex(delta, x0, &x0_inv)) return false;
+        if constexpr (has_sqrt_or_nr<F>()) {
+            // Of delta+ = (a0 + alpha)/2 and delta- = NR (a1/2)^2 / delta+ exactly one is a square.  ONE exponentiation decides
+            // and serves both: if delta+ is a square, x0 = sqrt(delta+), x1 = a1 / (2 x0); if not, with s = sqrt(NR delta+)
+            // (sqrt_or_nr) x0 = sqrt(delta-) = NR (a1/2) / s and x1 = a1 / (2 x0) = s / NR — no second exponentiation (every
+            // wave used to pay it: one lane in two needs the other candidate).
+            static_assert(F::Params::SQRT_NR == NR, "the base field's tower constants are for another non-residue");
+            F s, s_inv;
+            bool residue;
+            if (!F::sqrt_or_nr(delta, s, s_inv, residue)) return false;
+            if (s.is_zero()) return false;
+            const F half_a1 = F::mul(a.c1, two_inv);
+            if (residue) out = {s, F::mul(half_a1, s_inv)};
+            else out = {F::mul_small(F::mul(half_a1, s_inv), NR), F::mul(s, F::load_const(F::Params::SQRT_NR_INV))};
+            return sqr(out) == a;
+        } else {
+            F x0, x0_inv;
+            if (!F::sqrt_ex(delta, x0, &x0_inv)) {
+                delta = F::mul(F::sub(a.c0, alpha), two_inv);
+                if (!F::sqrt_ex(delta, x0, &x0_inv)) return false;
+            }
+            if (x0.is_zero()) return false;
+            F x1 = F::mul(F::mul(a.c1, two_inv), x0_inv);
+            out = {x0, x1};
+            return sqr(out) == a;
         }
-        if (x0.is_zero()) return false;
-        F x1 = F::mul(F::mul(a.c1, two_inv), x0_inv);
-        out = {x0, x1};
-        return sqr(out) == a;
     }
     PTAU_HD static bool read_bytes(const uint8_t *in, bool with_flags, uint8_t *flags, Fp2 &out) {
         uint8_t dummy = 0;

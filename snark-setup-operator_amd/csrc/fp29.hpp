@@ -422,6 +422,55 @@ struct Fp29 {
         if (inv_out) *inv_out = mul(out, sqr(mul(w, gd)));
         return true;
     }
+    // For the square roots of Fq[u]/(u^2 - nr) (ext.hpp): out = sqrt(a), residue = true — or, when a is NOT a square,
+    // out = sqrt(nr a), residue = false (nr = P::SQRT_NR, the tower's non-residue: nr a is a square then).  inv_out = 1/out.
+    // One exponentiation serves both cases: (nr a)^((T-1)/2) = SQRT_NR_C a^((T-1)/2); a non-residue shows at the FIRST window of
+    // the Pohlig-Hellman stage (a^T has full order 2^S, its 2^(E-W)-th power is no 2^W-th root of unity).
+    static constexpr bool HAS_SQRT_OR_NR = P::SQRT_NR != 0 && P::SQRT_W > 0;
+    __host__ __device__ __noinline__ static bool sqrt_or_nr(const Fp29 &a, Fp29 &out, Fp29 &inv_out, bool &residue) {
+        residue = true;
+        if (a.is_zero()) {
+            out = zero();
+            inv_out = zero();
+            return true;
+        }
+        Fp29 w = pow_limbs(a, P::TS_TM1H, P::TS_TM1H_BITS - 1);
+        Fp29 aa = a;
+        constexpr int E = P::TS_S - 1, W = P::SQRT_W;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            const Fp29 x = mul(aa, w);
+            Fp29 b = mul(x, w);
+            Fp29 gd = one();
+            bool fail = false;
+            for (int j = 0; j < P::SQRT_L; j++) {
+                const int wj = (E - W * j) < W ? (E - W * j) : W;
+                const int sh = E - W * j - wj;
+                Fp29 t = b;
+                for (int k = 0; k < sh; k++) t = sqr(t);
+                const uint32_t lo = t.l[0];
+                int K = -1;
+                for (int k = 0; k < (1 << W); k++) K = (P::SQRT_ZLOW[k] == lo) ? k : K;
+                if (K < 0) { fail = true; break; }
+                const int d = K >> (W - wj);
+                Fp29 f;
+#pragma unroll
+                for (int i = 0; i < N; i++) f.l[i] = P::SQRT_GNEG[(j << W) + d][i];
+                gd = mul(gd, f);
+                b = mul(b, sqr(f));
+            }
+            if (!fail) {
+                out = mul(x, gd);
+                if (sqr(out) != aa) return false;
+                inv_out = mul(out, sqr(mul(w, gd)));
+                return true;
+            }
+            if (attempt) return false;
+            residue = false;
+            aa = mul_small(a, P::SQRT_NR);
+            w = mul(w, load_const(P::SQRT_NR_C));
+        }
+        return false;
+    }
     PTAU_HD static bool sqrt(const Fp29 &a, Fp29 &out) { return sqrt_ex(a, out, nullptr); }
 
     // ---- canonical little-endian bytes (arkworks serialize) ----

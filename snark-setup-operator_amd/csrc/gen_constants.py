@@ -23,6 +23,7 @@ RADIX29 = {"BlsFq", "Mnt4Fq", "Mnt6Fq", "Bw6Fq"}
 # BW6-761 (round 2): 28 limbs of 29 bits — one more than ceil(761 / 29) — so that the element splits evenly over a lane pair
 # (fpl.hpp); its single-lane kernels (verify path) use the same representation so both kinds of kernel exchange values limb for limb.
 RADIX29_LIMBS = {"Bw6Fq": 28}
+TOWER_NR = {"BlsFq": -5, "Mnt4Fq": 13}   # the quadratic non-residue of the curve's Fq2 (G2 of BLS12-377 / MNT4-753)
 LAZY28 = {"BlsFq", "Bw6Fq"}      # base fields that also get a carry-free 28-bit twin (fpz.hpp; lane-split: fplz.hpp)
 # ... and the 753-bit fields of the MNT cycle: 28 limbs of 28 bits over a lane pair (two more than the 26 x 29-bit reduced form),
 # R = 2^784 >= 2^31 p — a != 0 curves: no common-Z table, Jacobian table entries, lazy_a.hpp
@@ -123,7 +124,7 @@ def limbs(x, n, lb=None):
     return ", ".join("0x%08xu" % ((x >> (lb * i)) & ((1 << lb) - 1)) for i in range(n))
 
 
-def field(name, p, cubic_nr=None, sqrt_tables=False, lb=32, n_limbs=None):
+def field(name, p, cubic_nr=None, sqrt_tables=False, lb=32, n_limbs=None, tower_nr=None):
     """Parameter struct of one prime field.  lb = 32: full 32-bit limbs (Fp, fp.hpp).  lb = 29: reduced radix (Fp29,
     fp29.hpp): ceil(bits/29) limbs of 29 bits, R = 2^(29 N), so that the 2N products of a product-scanning column fit a
     64-bit accumulator and the multiply-accumulate needs no carry instruction.  Exponents and the *32 arrays stay packed."""
@@ -193,6 +194,15 @@ def field(name, p, cubic_nr=None, sqrt_tables=False, lb=32, n_limbs=None):
         else:
             s.append("  static constexpr uint32_t SQRT_ZLOW[1] = {0};")
             s.append("  static constexpr uint32_t SQRT_GNEG[1][%d] = {{0}};" % n)
+    if tower_nr is not None and sqrt_tables:
+        # square roots in Fq[u]/(u^2 - nr) (ext.hpp Fp2::sqrt): of the two candidates delta+ / delta- = nr (a1/2)^2 / delta+ exactly
+        # one is a residue; when delta+ is not, nr delta+ is, and its (T-1)/2-th power is SQRT_NR_C times the one already computed
+        assert pow(tower_nr % p, (p - 1) // 2, p) == p - 1
+        s.append("  static constexpr int SQRT_NR = %d;" % tower_nr)
+        s.append("  static constexpr uint32_t SQRT_NR_C[%d] = {%s};     // nr^((T-1)/2), Montgomery" % (n, limbs(pow(tower_nr % p, (T - 1) // 2, p) * R % p, n)))
+        s.append("  static constexpr uint32_t SQRT_NR_INV[%d] = {%s};   // 1/nr, Montgomery" % (n, limbs(pow(tower_nr % p, -1, p) * R % p, n)))
+    else:
+        s.append("  static constexpr int SQRT_NR = 0;")
     if cubic_nr is not None:
         # Frobenius on Fq[u]/(u^3 - nr): (a0, a1, a2)^q = (a0, a1*c1, a2*c1^2), c1 = nr^((q-1)/3)
         c1 = pow(cubic_nr, (p - 1) // 3, p)
@@ -210,7 +220,7 @@ def main():
     out = ["// GENERATED by gen_constants.py — do not edit.", "#pragma once", "#include <cstdint>", "namespace ptau {"]
     fields = {}
     for name, p in (("BlsFq", BLS_Q), ("BlsFr", BLS_R), ("Bw6Fq", BW6_Q), ("Mnt4Fq", MNT_A), ("Mnt6Fq", MNT_B)):
-        txt, n, R = field(name, p, cubic_nr=11 if name == "Mnt6Fq" else None, sqrt_tables=name.endswith("Fq"))
+        txt, n, R = field(name, p, cubic_nr=11 if name == "Mnt6Fq" else None, sqrt_tables=name.endswith("Fq"), tower_nr=TOWER_NR.get(name))
         fields[name] = (p, n, R, 32)
         out.append(txt)
     # reduced-radix twins for the base fields of the curves listed in RADIX29 (the radix-32 structs stay: they are also the
@@ -218,7 +228,7 @@ def main():
     for name, p in (("BlsFq", BLS_Q), ("Bw6Fq", BW6_Q), ("Mnt4Fq", MNT_A), ("Mnt6Fq", MNT_B)):
         if name in RADIX29:
             txt, n, R = field(name + "R29", p, cubic_nr=11 if name == "Mnt6Fq" else None, sqrt_tables=True, lb=29,
-                              n_limbs=RADIX29_LIMBS.get(name))
+                              n_limbs=RADIX29_LIMBS.get(name), tower_nr=TOWER_NR.get(name))
             fields[name + "R29"] = (p, n, R, 29)
             out.append(txt)
     # carry-free ("lazy") twin of a base field for the inner loop of K1 (fpz.hpp): 28-bit limbs, one limb more than the
