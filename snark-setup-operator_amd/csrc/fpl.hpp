@@ -609,6 +609,52 @@ struct FpL {
         if (inv_out) *inv_out = mul(out, sqr(mul(w, gd)));
         return ok;
     }
+    // Fp29::sqrt_or_nr on the pair (the square roots of Fq[u]/(u^2 - nr), ext.hpp): out = sqrt(a), residue = true, or
+    // out = sqrt(nr a), residue = false; inv_out = 1/out.  The lookup key is broadcast from the even lane, so both lanes of a
+    // pair take the same branches.
+    static constexpr bool HAS_SQRT_OR_NR = P::SQRT_NR != 0 && P::SQRT_W > 0;
+    __device__ __noinline__ static bool sqrt_or_nr(const FpL &a, FpL &out, FpL &inv_out, bool &residue) {
+        residue = true;
+        if (a.is_zero()) {
+            out = zero();
+            inv_out = zero();
+            return true;
+        }
+        FpL w = pow_limbs(a, P::TS_TM1H, P::TS_TM1H_BITS - 1);
+        FpL aa = a;
+        constexpr int E = P::TS_S - 1, W = P::SQRT_W;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            const FpL x = mul(aa, w);
+            FpL b = mul(x, w);
+            FpL gd = one();
+            bool fail = false;
+            for (int j = 0; j < P::SQRT_L; j++) {
+                const int wj = (E - W * j) < W ? (E - W * j) : W;
+                const int sh = E - W * j - wj;
+                FpL t = b;
+                for (int k = 0; k < sh; k++) t = sqr(t);
+                const uint32_t lo = lane_bcast_even(t.l[0]);
+                int K = -1;
+                for (int k = 0; k < (1 << W); k++) K = (P::SQRT_ZLOW[k] == lo) ? k : K;
+                if (K < 0) { fail = true; break; }
+                const int d = K >> (W - wj);
+                const FpL f = load_const(P::SQRT_GNEG[(j << W) + d]);
+                gd = mul(gd, f);
+                b = mul(b, sqr(f));
+            }
+            if (!fail) {
+                out = mul(x, gd);
+                if (sqr(out) != aa) return false;
+                inv_out = mul(out, sqr(mul(w, gd)));
+                return true;
+            }
+            if (attempt) return false;
+            residue = false;
+            aa = mul_small(a, P::SQRT_NR);
+            w = mul(w, load_const(P::SQRT_NR_C));
+        }
+        return false;
+    }
     PTAU_HD static bool sqrt(const FpL &a, FpL &out) { return sqrt_ex(a, out, nullptr); }
     PTAU_HD static bool read_bytes(const uint8_t *in, bool with_flags, uint8_t *flags, FpL &out) {
         Full f;
