@@ -317,7 +317,7 @@ int run_apply_powers_dev(DeviceCtx *c, int curve, int group, const GroupOps *ops
         // endomorphism kernel is queued behind the sums at once — SPECULATIVELY, beside the tests.  The verdict is read when
         // both are done; if it is "not a subgroup vector" (or not even valid points) the result is thrown away and the plain
         // path runs, which reports bad points as it always did.  Short vectors: the exact test where it is cheap (BLS12-377 G2).
-        const bool batched = ops->has_endo_mul && n > BATCHED_SUBGROUP_MIN && use_batched_subgroup() && !cin &&
+        const bool batched = ops->auto_probe_pays && n > BATCHED_SUBGROUP_MIN && use_batched_subgroup() && !cin &&
                              !cofactor_is_one(curve, group);
         if (batched) {
             int rc = enqueue_batched_subgroup_dev(c, curve, group, ops, d_in, cin, n, err);

@@ -1744,6 +1744,10 @@ struct GroupOps {
     bool membership_cheap;
     // the group has an endomorphism-accelerated multiplication at all (GLV / GLS; use_glv of window_scalar_mul is honoured)
     bool has_endo_mul;
+    // ... and the batched membership probe of BatchExpMode::Auto costs less than the endomorphism saves.  Not on the MNT4-753
+    // twist: its 2^16-point probe (16 ms of bucket sums in the single-lane Fq2 + the psi tests beside K1) and the GLS saving
+    // (13 ms) cancel — 0.57 against 0.59 M updates/s measured; MNT6-753 G2 gains 18 %, BW6-761 8 %, BLS12-377 17 % / 49 %
+    bool auto_probe_pays;
     // membership through psi (MNT twists): K1 with the fixed scalar psi_scalar (fr_limbs32 words), then psi_check on its result
     const uint32_t *psi_scalar;
     void (*psi_check)(hipStream_t, const uint8_t *in, int cin, const void *scratch, uint64_t n, int *err);
@@ -1968,6 +1972,7 @@ struct Launch {
         o.membership_cheap = G::J::CfgT::ENDO_KIND == 2 && Fr::N == 8;
         o.has_endo_mul = G::J::CfgT::GLV_KIND != 0 || (G::J::CfgT::ENDO_KIND == 2 && Fr::N == 8);
         if constexpr (!std::is_void_v<GA>) o.has_endo_mul = o.has_endo_mul || GA::HAS_GLS;
+        o.auto_probe_pays = o.has_endo_mul && !(G::J::CfgT::PSI_KIND == 1 && G::F::DEG == 2);
         if constexpr (G::J::CfgT::PSI_KIND == 1) {
             static_assert(sizeof(G::J::CfgT::PSI_N) / 4 == Fr::N, "psi scalar must have the scalar field's word count");
             o.psi_scalar = G::J::CfgT::PSI_N;
