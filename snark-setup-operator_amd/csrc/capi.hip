@@ -8,6 +8,8 @@
 
 #include <fcntl.h>
 #include <sys/mman.h>
+#include <sys/resource.h>
+#include <sys/syscall.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -22,6 +24,7 @@
 #include <thread>
 #include <deque>
 #include <condition_variable>
+#include <functional>
 #include <future>
 #include <memory>
 #include <mutex>
@@ -82,6 +85,15 @@ const ptau::PairingOps *get_pairing_ops(int curve) {
         if (e_ != hipSuccess)                                                                      \
             return err.fail(PTAU_E_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_));         \
     } while (0)
+
+// Host worker threads that only stream bytes (BLAKE2b of a file, page population) step back behind the threads that feed the
+// GPU: with several in-process lanes on a box with fewer cores than threads, a lane's launching thread that waits for a CPU
+// leaves the device idle inside the section that holds the device lock (measured: 8 lanes on 16 threads, 150 ms of "device
+// section" for 98 ms of kernels).  Raising one's own niceness needs no privilege; PTAU_NICE_WORKERS=0 turns it off.
+inline void background_worker() {
+    static const bool on = [] { const char *e = getenv("PTAU_NICE_WORKERS"); return !(e && e[0] == '0'); }();
+    if (on) (void)setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), 10);
+}
 
 // PTAU_TRACE=1: wall-clock marks of the file-level calls on stderr (where the host time of a call goes)
 struct Trace {
@@ -196,6 +208,10 @@ struct DeviceCtx {
         uint64_t points = 0;
         bool probe = false;   // a membership probe: its main-stream time is membership time, there are no sums to fetch
     } tail;
+    // verify / combine: the D2H of a decompressed vector is queued on the copy stream and NOT waited for (CopyTrack); the next
+    // writer of the same output buffer waits for it on the device
+    hipEvent_t bufev[2] = {};
+    bool buf_copying[2] = {false, false};
     int cus = 0;   // compute units of the device
     ptau_timing timing = {};
     double busy_ms = 0;   // kernel time since the library was loaded, every call on this device (under mu)
@@ -224,13 +240,26 @@ int ensure_ctx(int device, DeviceCtx *&c, const Err &err, bool side = false) {
     std::lock_guard<std::mutex> init_lk(g_init_mu);
     if (c->ready) return PTAU_OK;
     hipStream_t st[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t evs[14] = {};
+    hipEvent_t evs[16] = {};
     void *bufs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     const size_t buf_sz[5] = {sizeof(uint32_t) * (1 + ptau::SCALAR_TABLE_ENTRIES) * 24, 256, 4096, 16384, TB_SIZE};
     hipError_t e = hipSuccess;
     const char *what = "";
-    for (int i = 0; i < 5 && e == hipSuccess; i++) { e = hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking); what = "hipStreamCreateWithFlags"; }
-    for (int i = 0; i < 14 && e == hipSuccess; i++) { e = hipEventCreate(&evs[i]); what = "hipEventCreate"; }
+    // Streams of one priority share a small pool of hardware queues (four by default), and two streams on one queue run
+    // their kernels strictly one after the other: measured with four lanes, the tail stream's kernels never overlapped ANY
+    // lane's 50 ms pairing kernel — every verification waited for somebody's pairing inside its device section (+51 ms).
+    // So the three kinds of work get three priorities, i.e. three pools: the few-wave kernels a lane waits for (MSM tails,
+    // bucket tests) high, the long kernels nobody waits for inside a device section (pairing, the lone beta_g2 element) low,
+    // vector kernels and copies normal.  The side context (contribute's beta_g2) only ever uses its main and copy streams.
+    int prio_least = 0, prio_greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) { (void)hipGetLastError(); prio_least = prio_greatest = 0; }
+    const int prio[5] = {0, prio_least, 0, prio_least, prio_greatest};   // main, side, copy, pair, tail
+    for (int i = 0; i < 5 && e == hipSuccess; i++) {
+        if (side && i != 0 && i != 2) continue;
+        e = hipStreamCreateWithPriority(&st[i], hipStreamNonBlocking, std::min(std::max(prio[i], prio_greatest), prio_least));
+        what = "hipStreamCreateWithPriority";
+    }
+    for (int i = 0; i < 16 && e == hipSuccess; i++) { e = hipEventCreate(&evs[i]); what = "hipEventCreate"; }
     for (int i = 0; i < 5 && e == hipSuccess; i++) { e = hipMalloc(&bufs[i], buf_sz[i]); what = "hipMalloc"; }
     if (e != hipSuccess) {
         for (auto s : st) if (s) (void)hipStreamDestroy(s);
@@ -249,6 +278,8 @@ int ensure_ctx(int device, DeviceCtx *&c, const Err &err, bool side = false) {
     for (int i = 0; i < 4; i++) c->tev[i] = evs[8 + i];
     c->pev[0] = evs[12];
     c->pev[1] = evs[13];
+    c->bufev[0] = evs[14];
+    c->bufev[1] = evs[15];
     c->t_buf = (uint8_t *)bufs[4];
     c->bk_table = (uint32_t *)(c->t_buf + TB_TABLE);
     c->d_table = (uint32_t *)bufs[0];
@@ -910,18 +941,71 @@ int flush_pending_copy(DeviceCtx *c, const Err &err) {
     return PTAU_OK;
 }
 
+// Device-to-host copies of a verification that nobody waits for inside the device section: each is queued on the copy stream
+// between two host callbacks — the first takes the time, the second adds the elapsed time to the call's d2h total, publishes
+// the progress mark of the streaming new-challenge hash and counts the copy as landed.  The owner (verify_chunk_impl,
+// combine_impl) calls drain() before its buffers go away, on every path.  With a destination that is not registered with the
+// HIP runtime hipMemcpyAsync is a blocking staged copy: still correct, only not overlapped.
+struct CopyTrack {
+    std::atomic<int64_t> d2h_ns{0};
+    std::atomic<int> outstanding{0};
+    struct Node {
+        CopyTrack *t;
+        std::atomic<size_t> *ready;
+        size_t mark;
+        std::chrono::steady_clock::time_point t0;
+    };
+    static void on_start(void *u) { ((Node *)u)->t0 = std::chrono::steady_clock::now(); }
+    static void on_end(void *u) {
+        Node *n = (Node *)u;
+        n->t->d2h_ns.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - n->t0).count());
+        if (n->ready) n->ready->store(n->mark, std::memory_order_release);
+        CopyTrack *t = n->t;
+        delete n;
+        t->outstanding.fetch_sub(1, std::memory_order_release);
+    }
+    void drain() const {
+        while (outstanding.load(std::memory_order_acquire) > 0) usleep(50);
+    }
+    ~CopyTrack() { drain(); }
+};
+int start_vector_copy(DeviceCtx *c, CopyTrack *track, int sel, const void *src, uint8_t *dst, size_t bytes, std::atomic<size_t> *ready,
+                      size_t mark, const Err &err) {
+    CopyTrack::Node *node = new CopyTrack::Node{track, ready, mark, {}};
+    track->outstanding.fetch_add(1, std::memory_order_acq_rel);
+    hipError_t e = hipLaunchHostFunc(c->copy_stream, CopyTrack::on_start, node);
+    if (e == hipSuccess) e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->copy_stream);
+    if (e == hipSuccess) e = hipEventRecord(c->bufev[sel], c->copy_stream);
+    if (e == hipSuccess) e = hipLaunchHostFunc(c->copy_stream, CopyTrack::on_end, node);
+    if (e != hipSuccess) {   // the end callback will not run: settle the node here, after whatever was queued
+        (void)hipStreamSynchronize(c->copy_stream);
+        delete node;
+        track->outstanding.fetch_sub(1, std::memory_order_release);
+        return err.fail(PTAU_E_DEVICE, "queueing a device-to-host copy failed: %s", hipGetErrorString(e));
+    }
+    c->buf_copying[sel] = true;
+    return PTAU_OK;
+}
+
 // One response vector of a chunk: compressed host bytes -> (sqrt) -> non-zero / subgroup checks -> uncompressed
 // host bytes of the next challenge.  Caller holds the device mutex.
 int run_verify_vector(DeviceCtx *c, int curve, int group, const GroupOps *ops, const uint8_t *in, uint8_t *out, uint64_t n,
                       int check_output, int subgroup_check_mode, const uint64_t *ratio_seed, uint64_t index_base,
-                      uint8_t *pair_a, uint8_t *pair_b, std::atomic<size_t> *ready, size_t ready_mark, const Err &err) {
+                      uint8_t *pair_a, uint8_t *pair_b, std::atomic<size_t> *ready, size_t ready_mark, CopyTrack *track, const Err &err) {
     if (!n) return PTAU_OK;
     int rc;
-    void *&d_out = c->out_sel ? c->d_out_alt : c->d_out;
-    size_t &d_out_cap = c->out_sel ? c->out_alt_cap : c->out_cap;
+    const int sel = c->out_sel;
+    void *&d_out = sel ? c->d_out_alt : c->d_out;
+    size_t &d_out_cap = sel ? c->out_alt_cap : c->out_cap;
     c->out_sel ^= 1;
     if ((rc = grow(c->d_in, c->in_cap, n * ops->comp, err))) return rc;
+    if (d_out_cap < n * ops->uncomp && c->buf_copying[sel]) {   // about to be reallocated: its last reader must be done
+        HIP_TRY(hipEventSynchronize(c->bufev[sel]));
+        c->buf_copying[sel] = false;
+    }
     if ((rc = grow(d_out, d_out_cap, n * ops->uncomp, err))) return rc;
+    // the copy that last read this output buffer (two vectors ago, or another lane's) finishes before it is overwritten
+    if (c->buf_copying[sel]) HIP_TRY(hipStreamWaitEvent(c->stream, c->bufev[sel], 0));
     float ms = 0;
     HIP_TRY(hipEventRecord(c->ev[3], c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_in, in, n * ops->comp, hipMemcpyHostToDevice, c->stream));
@@ -939,10 +1023,8 @@ int run_verify_vector(DeviceCtx *c, int curve, int group, const GroupOps *ops, c
                        (subgroup_check_mode == PTAU_SUBGROUP_AUTO || subgroup_check_mode == PTAU_SUBGROUP_BATCHED) &&
                        !cofactor_is_one(curve, group);
     if (fused) want_subgroup = false;
-    // the membership kernels are queued behind the decompression at once (one error word collects both), so that the
-    // previous vector's deferred copy below has real work to hide behind
+    // the membership kernels are queued behind the decompression at once (one error word collects both)
     if (want_subgroup && (rc = enqueue_subgroup_kernels(c, curve, group, ops, (const uint8_t *)d_out, 0, n, err))) return rc;
-    if ((rc = flush_pending_copy(c, err))) return rc;
     int bits = 0;
     HIP_TRY(hipMemcpyAsync(&bits, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -968,12 +1050,8 @@ int run_verify_vector(DeviceCtx *c, int curve, int group, const GroupOps *ops, c
         const MsmFuse fz{curve, group};
         if ((rc = run_msm_dev(c, ops, (const uint8_t *)d_out, 0, n - 1, src, pair_a, pair_b, 0, err, /*defer_tail=*/true, fused ? &fz : nullptr))) return rc;
     }
-    c->pending.src = d_out;
-    c->pending.dst = out;
-    c->pending.bytes = n * ops->uncomp;
-    c->pending.ready = ready;
-    c->pending.mark = ready_mark;
-    return PTAU_OK;
+    // the decompressed vector goes home on the copy stream; nobody waits for it here
+    return start_vector_copy(c, track, sel, d_out, out, n * ops->uncomp, ready, ready_mark, err);
 }
 
 // The single beta_g2 element of a chunk on the side stream: H2D, decompress (+ non-zero test), membership test, D2H of
@@ -1125,6 +1203,7 @@ struct MappedFile {
             if (p == MAP_FAILED) return err.fail(PTAU_E_IO, "cannot mmap %s: %s", path, strerror(errno));
             if (pin && want_register()) {
                 populate = std::async(std::launch::async, [this, device] {
+                    background_worker();
 #ifndef MADV_POPULATE_READ
 #define MADV_POPULATE_READ 22
 #endif
@@ -1154,6 +1233,7 @@ struct MappedFile {
         // populated range is then page-locked and registered with the HIP runtime (DMA straight into the file's pages,
         // no bounce buffer) unless PTAU_HOST_REGISTER=0.
         populate = std::async(std::launch::async, [this, device] {
+            background_worker();
 #ifndef MADV_POPULATE_WRITE
 #define MADV_POPULATE_WRITE 23
 #endif
@@ -1400,8 +1480,9 @@ int ptau_contribute_file(const ptau_params *p, const char *challenge_path, const
     {   // BLAKE2b(challenge) on a host thread while the GPU updates the elements
         const uint8_t *chp = (const uint8_t *)ch.p;
         const size_t chl = ch.len;
-        auto fut = std::async(std::launch::async, [chp, chl, &digest] { ptau_blake2b512(chp, chl, digest); });
+        auto fut = std::async(std::launch::async, [chp, chl, &digest] { background_worker(); ptau_blake2b512(chp, chl, digest); });
         ch.wait_pinned();
+        resp.wait_pinned();   // (BLAKE2b(challenge) is running: 0.36 s, the device needs half of that)
         rc = ptau_phase1_computation(p, chp, chl, out, resp.len, tau, alpha, beta, check_input, batch_exp_mode, device, errbuf, err_len);
         fut.get();
         if (rc) return rc;
@@ -1446,11 +1527,13 @@ int ptau_contribute_file_seeded(const ptau_params *p, const char *challenge_path
         const int curve = p->curve;
         char kmsg[256] = {0};
         auto fut = std::async(std::launch::async, [&, chp, chl, curve] {
+            background_worker();
             ptau_blake2b512(chp, chl, digest);
             uint64_t t2[12], a2[12], b2[12];
             return ptau_key_generation(curve, seed, seed_len, digest, t2, a2, b2, pk.data(), pk.size(), kmsg, sizeof(kmsg));
         });
         ch.wait_pinned();
+        resp.wait_pinned();   // (BLAKE2b(challenge) is running: 0.36 s, the device needs half of that)
         rc = ptau_phase1_computation(p, chp, chl, out, resp.len, tau, alpha, beta, check_input, batch_exp_mode, device, errbuf, err_len);
         const int krc = fut.get();
         if (rc) return rc;
@@ -1676,7 +1759,8 @@ int collect_pok_jobs(const ptau_params *p, const ptau_sizes &sz, const uint8_t *
 int verify_chunk_impl(const ptau_params *p, const uint8_t *challenge, size_t challenge_len, const uint8_t *response,
                       size_t response_len, uint8_t *new_challenge, size_t new_challenge_len, int check_input,
                       int check_output, int subgroup_check_mode, int ratio_check, int verify_pok, const uint8_t *g2_s,
-                      const uint8_t *tau_g2_check, int device, VerifyDigests *digests, char *errbuf, size_t err_len) {
+                      const uint8_t *tau_g2_check, int device, VerifyDigests *digests, char *errbuf, size_t err_len,
+                      const std::function<void()> *before_device = nullptr) {
     Err err{errbuf, err_len};
     int rc = check_params(p, err);
     if (rc) return rc;
@@ -1696,11 +1780,13 @@ int verify_chunk_impl(const ptau_params *p, const uint8_t *challenge, size_t cha
     // and would otherwise cost as much as the device work — SURVEY §7 hard part 7).
     uint8_t chal_digest[64];
     auto fut_chain = std::async(std::launch::async, [=, &chal_digest] {
+        background_worker();
         ptau_blake2b512(challenge, challenge_len, chal_digest);
         if (digests) memcpy(digests->challenge, chal_digest, 64);
         return memcmp(chal_digest, response, 64) == 0;
     });
     std::shared_future<void> fut_resp = std::async(std::launch::async, [=] {
+        background_worker();
         ptau_blake2b512(response, response_len, new_challenge);
         if (digests) memcpy(digests->response, new_challenge, 64);
     }).share();
@@ -1709,6 +1795,7 @@ int verify_chunk_impl(const ptau_params *p, const uint8_t *challenge, size_t cha
     std::future<void> fut_nc;
     if (digests)
         fut_nc = std::async(std::launch::async, [&, fut_resp] {
+            background_worker();
             fut_resp.wait();
             Blake2b b;
             size_t done = 0;
@@ -1737,10 +1824,15 @@ int verify_chunk_impl(const ptau_params *p, const uint8_t *challenge, size_t cha
             if (c.valid()) c.wait();
         }
     } joiner{fut_chain, fut_resp, fut_nc, nc_abort};
+    CopyTrack track;   // (after the joiner: it drains first, while nc_ready and the caller's buffers are certainly alive)
     const GroupOps *g1 = get_ops(p->curve, 1), *g2 = get_ops(p->curve, 2);
     DeviceCtx *c;
     if ((rc = ensure_ctx(device, c, err))) return rc;
     Trace tr{"  verify_chunk"};
+    // the digests are running; whatever the caller still has to wait for before the device can be used well (file-level
+    // call: the output mapping's page registration, ~115 ms for 503 MB) is waited for HERE, outside the device lock.  It costs
+    // no latency: BLAKE2b(new challenge) cannot start before BLAKE2b(response) has produced its header (~180 ms).
+    if (before_device) (*before_device)();
     std::unique_lock<std::mutex> lk(c->mu);   // held for the device section only: pairings and digests below run unlocked
     tr.mark("device lock taken");
     HIP_TRY(hipSetDevice(device));
@@ -1780,23 +1872,25 @@ int verify_chunk_impl(const ptau_params *p, const uint8_t *challenge, size_t cha
         uint8_t *pa = pairs.data() + (size_t)k * 2 * g2->uncomp, *pb = pa + g2->uncomp;
         if ((rc = run_verify_vector(c, p->curve, v.group, v.ops, pi, po, v.n, check_output, subgroup_check_mode,
                                     ratio_check ? seed : nullptr, sz.start, pa, pb, &nc_ready,
-                                    (size_t)(po + v.n * v.ops->uncomp - new_challenge), err))) {
+                                    (size_t)(po + v.n * v.ops->uncomp - new_challenge), &track, err))) {
             hipStreamSynchronize(c->side_stream);   // never leave device work running past the caller's buffers
             return rc;
         }
         pi += v.n * v.ops->comp;
         po += v.n * v.ops->uncomp;
     }
-    if ((rc = flush_pending_copy(c, err)) || (rc = finish_msm_tail(c, err, nullptr))) {   // the last vector's copy and MSM tail
+    if ((rc = finish_msm_tail(c, err, nullptr))) {   // the last vector's MSM tail
         hipStreamSynchronize(c->side_stream);
         return rc;
     }
     vec_out[4] = po;
     if ((rc = finish_single_side(c, err))) return rc;
     po += g2->uncomp;
-    nc_ready.store((size_t)(po - new_challenge), std::memory_order_release);
     lk.unlock();   // another lane may use the device while this one finishes its host tail
     tr.mark("device section done");
+    track.drain();   // the vectors' copies (queued, never waited for inside the device section) have landed
+    nc_ready.store((size_t)(po - new_challenge), std::memory_order_release);
+    tr.mark("copies landed");
     // ---- host tail: every same-ratio check of this verification, one host thread each ----
     std::vector<RatioJob> ratio_jobs, pok_jobs;
     if (ratio_check) {
@@ -1847,6 +1941,7 @@ int verify_chunk_impl(const ptau_params *p, const uint8_t *challenge, size_t cha
         std::lock_guard<std::mutex> tl(c->mu);
         c->timing.ratio_checks = (uint32_t)ratio_jobs.size();
         c->timing.pok_checks = (uint32_t)pok_jobs.size();
+        c->timing.d2h_ms += (double)track.d2h_ns.load() / 1e6;
     }
     // new_challenge = BLAKE2b(response) | decompressed elements
     fut_resp.wait();
@@ -1895,10 +1990,16 @@ int ptau_transform_pok_and_correctness_file(const ptau_params *p, const char *ch
     if ((rc = nc.create_new(new_challenge_path, sz.accumulator_size, err, device))) return rc;
     VerifyDigests dg;
     tr.mark("files mapped");
-    resp.wait_pinned();
-    tr.mark("response pinned");
+    // input and output mappings are pinned before the device section starts (every copy is then DMA at full rate and the
+    // section is as short as its kernels: it holds the device lock), but AFTER the digests have started
+    const std::function<void()> pin_wait = [&] {
+        resp.wait_pinned();
+        nc.wait_pinned();
+        tr.mark("mappings pinned");
+    };
     rc = verify_chunk_impl(p, (const uint8_t *)ch.p, ch.len, (const uint8_t *)resp.p, resp.len, (uint8_t *)nc.p, nc.len, check_input,
-                           check_output, subgroup_check_mode, ratio_check, /*verify_pok=*/1, g2_s, tau_g2_check, device, &dg, errbuf, err_len);
+                           check_output, subgroup_check_mode, ratio_check, /*verify_pok=*/1, g2_s, tau_g2_check, device, &dg, errbuf, err_len,
+                           &pin_wait);
     tr.mark("verify_chunk_impl done");
     // the reference writes challenge.hash and response.hash before it verifies: keep them on the failure paths that got that far
     if (rc == PTAU_OK || rc == PTAU_E_HASH_CHAIN || rc == PTAU_E_INVALID_RATIO || rc == PTAU_E_NOT_IN_SUBGROUP ||
@@ -2133,6 +2234,7 @@ int combine_impl(const ptau_params *full, uint64_t chunk_size, const uint8_t *co
     DeviceCtx *c;
     if ((rc = ensure_ctx(device, c, err))) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
+    CopyTrack track;   // (after the lock: drained before the device is released and before the caller's buffers go away)
     HIP_TRY(hipSetDevice(device));
     c->timing = ptau_timing{};
     c->pending.bytes = 0;   // a copy left pending by a call that failed must never land
@@ -2163,12 +2265,14 @@ int combine_impl(const ptau_params *full, uint64_t chunk_size, const uint8_t *co
             const uint64_t stored = j == 4 ? 1 : v[j].n;   // every chunk stores beta_g2; only chunk 0's is kept
             if (v[j].n &&
                 (rc = run_verify_vector(c, full->curve, v[j].group, v[j].ops, pi, v[j].dst, v[j].n, PTAU_CHECK_NO,
-                                        PTAU_SUBGROUP_NO, nullptr, 0, nullptr, nullptr, nullptr, 0, err)))
+                                        PTAU_SUBGROUP_NO, nullptr, 0, nullptr, nullptr, nullptr, 0, &track, err)))
                 return rc;
             pi += stored * v[j].ops->comp;
         }
     }
-    return flush_pending_copy(c, err);   // the last vector's deferred copy
+    track.drain();   // every vector's copy has landed
+    c->timing.d2h_ms += (double)track.d2h_ns.load() / 1e6;
+    return PTAU_OK;
 }
 
 // pair-index range [lo, hi) of slice k of n_pairs over nd slices: contiguous, balanced to within one pair

@@ -22,6 +22,6 @@ for lanes in (1, 4, 8, 12):
         dt = time.perf_counter() - t0
         print("register=%s lanes %d: %.2f chunks/s busy %.2f" % (os.environ.get("PTAU_HOST_REGISTER", "1"), lanes, lanes / dt, (Lb.ptau_device_busy_ms(0) - b0) / 1e3 / dt), flush=True)
         tm = pkg.phase1_cli.last_timing(0)
-        print("   last call under load: kernel %.0f h2d %.1f d2h %.1f ms" % (tm["kernel_ms"], tm["h2d_ms"], tm["d2h_ms"]), flush=True)
+        print("   last call under load: kernel %.0f (decompress %.0f msm %.0f) h2d %.1f d2h %.1f ms" % (tm["kernel_ms"], tm["decompress_ms"], tm["msm_ms"], tm["h2d_ms"], tm["d2h_ms"]), flush=True)
         for k in range(lanes): os.remove(f("L%d.c1" % k))
 shutil.rmtree(d, ignore_errors=True)

@@ -42,6 +42,40 @@ def run(lg):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def run_lanes(lg, lanes):
+    """One warm verification, a pause, then `lanes` concurrent verifications of the same chunk (in-process lanes on one GPU):
+    `read` then shows how the device is shared."""
+    import shutil
+    import tempfile
+    import threading
+    from bench import load_pkg
+    pkg = load_pkg()
+    n = 1 << lg
+    prm = pkg.Phase1Parameters.new_chunk("bls12_377", 0, 0, n, 0, lg, n)
+    d = tempfile.mkdtemp(prefix="ptau_vl_", dir="/dev/shm" if os.access("/dev/shm", os.W_OK) else None)
+    f = lambda s: os.path.join(d, s)
+    try:
+        pkg.new_challenge(f("c0"), f("c0.hash"), prm)
+        pkg.phase1_cli.contribute_seeded(f("c0"), f("c0.h2"), f("r0"), f("r0.hash"), pkg.CheckForCorrectness.No, pkg.BatchExpMode.Auto,
+                                         prm, b"bench verify seed".ljust(64, b"."), device=0)
+
+        def lane(k):
+            pkg.transform_pok_and_correctness(f("c0"), f("L%d.c.hash" % k), pkg.CheckForCorrectness.No, f("r0"), f("L%d.r.hash" % k),
+                                              pkg.CheckForCorrectness.OnlyNonZero, f("L%d.c1" % k), f("L%d.c1.hash" % k), pkg.SubgroupCheckMode.Auto,
+                                              True, prm, device=0)
+        lane(99)
+        time.sleep(1.5)
+        th = [threading.Thread(target=lane, args=(k,)) for k in range(lanes)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        print("lanes", lanes, "chunks/s", lanes / (time.perf_counter() - t0), flush=True)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def run_contribute(lg, asserted):
     """Two contributions of chunk 0 (the second one is what `read` isolates): default flags, or membership asserted."""
     import shutil
@@ -111,6 +145,8 @@ def read(path):
 if __name__ == "__main__":
     if sys.argv[1] == "run":
         run(int(sys.argv[2]) if len(sys.argv) > 2 else 20)
+    elif sys.argv[1] == "lanes":
+        run_lanes(20, int(sys.argv[2]) if len(sys.argv) > 2 else 4)
     elif sys.argv[1] in ("contribute", "contribute_asserted"):
         run_contribute(int(sys.argv[2]) if len(sys.argv) > 2 else 20, sys.argv[1] == "contribute_asserted")
     else:
