@@ -949,6 +949,7 @@ int flush_pending_copy(DeviceCtx *c, const Err &err) {
 struct CopyTrack {
     std::atomic<int64_t> d2h_ns{0};
     std::atomic<int> outstanding{0};
+    hipStream_t stream = nullptr;
     struct Node {
         CopyTrack *t;
         std::atomic<size_t> *ready;
@@ -965,13 +966,21 @@ struct CopyTrack {
         t->outstanding.fetch_sub(1, std::memory_order_release);
     }
     void drain() const {
-        while (outstanding.load(std::memory_order_acquire) > 0) usleep(50);
+        for (unsigned spins = 1; outstanding.load(std::memory_order_acquire) > 0; spins++) {
+            usleep(50);
+            // a callback that can no longer come (the stream is idle, or the device is gone) must not hang the caller
+            if (spins % 2000 == 0 && stream && hipStreamQuery(stream) != hipErrorNotReady) {
+                usleep(2000);
+                if (outstanding.load(std::memory_order_acquire) > 0 && hipStreamQuery(stream) != hipErrorNotReady) break;
+            }
+        }
     }
     ~CopyTrack() { drain(); }
 };
 int start_vector_copy(DeviceCtx *c, CopyTrack *track, int sel, const void *src, uint8_t *dst, size_t bytes, std::atomic<size_t> *ready,
                       size_t mark, const Err &err) {
     CopyTrack::Node *node = new CopyTrack::Node{track, ready, mark, {}};
+    track->stream = c->copy_stream;
     track->outstanding.fetch_add(1, std::memory_order_acq_rel);
     hipError_t e = hipLaunchHostFunc(c->copy_stream, CopyTrack::on_start, node);
     if (e == hipSuccess) e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->copy_stream);
@@ -1480,7 +1489,7 @@ int ptau_contribute_file(const ptau_params *p, const char *challenge_path, const
     {   // BLAKE2b(challenge) on a host thread while the GPU updates the elements
         const uint8_t *chp = (const uint8_t *)ch.p;
         const size_t chl = ch.len;
-        auto fut = std::async(std::launch::async, [chp, chl, &digest] { background_worker(); ptau_blake2b512(chp, chl, digest); });
+        auto fut = std::async(std::launch::async, [chp, chl, &digest] { ptau_blake2b512(chp, chl, digest); });   // (critical path: not a background worker)
         ch.wait_pinned();
         resp.wait_pinned();   // (BLAKE2b(challenge) is running: 0.36 s, the device needs half of that)
         rc = ptau_phase1_computation(p, chp, chl, out, resp.len, tau, alpha, beta, check_input, batch_exp_mode, device, errbuf, err_len);
@@ -1526,8 +1535,7 @@ int ptau_contribute_file_seeded(const ptau_params *p, const char *challenge_path
         const size_t chl = ch.len;
         const int curve = p->curve;
         char kmsg[256] = {0};
-        auto fut = std::async(std::launch::async, [&, chp, chl, curve] {
-            background_worker();
+        auto fut = std::async(std::launch::async, [&, chp, chl, curve] {   // (critical path: not a background worker)
             ptau_blake2b512(chp, chl, digest);
             uint64_t t2[12], a2[12], b2[12];
             return ptau_key_generation(curve, seed, seed_len, digest, t2, a2, b2, pk.data(), pk.size(), kmsg, sizeof(kmsg));
