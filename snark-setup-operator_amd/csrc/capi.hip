@@ -1000,14 +1000,27 @@ int start_vector_copy(DeviceCtx *c, CopyTrack *track, int sel, const void *src, 
 // host bytes of the next challenge.  Caller holds the device mutex.
 int run_verify_vector(DeviceCtx *c, int curve, int group, const GroupOps *ops, const uint8_t *in, uint8_t *out, uint64_t n,
                       int check_output, int subgroup_check_mode, const uint64_t *ratio_seed, uint64_t index_base,
-                      uint8_t *pair_a, uint8_t *pair_b, std::atomic<size_t> *ready, size_t ready_mark, CopyTrack *track, const Err &err) {
+                      uint8_t *pair_a, uint8_t *pair_b, std::atomic<size_t> *ready, size_t ready_mark, CopyTrack *track, const Err &err,
+                      const uint8_t *next_in = nullptr, size_t next_bytes = 0) {
     if (!n) return PTAU_OK;
     int rc;
     const int sel = c->out_sel;
     void *&d_out = sel ? c->d_out_alt : c->d_out;
     size_t &d_out_cap = sel ? c->out_alt_cap : c->out_cap;
     c->out_sel ^= 1;
-    if ((rc = grow(c->d_in, c->in_cap, n * ops->comp, err))) return rc;
+    // the compressed input: copied while the previous vector's kernels ran (Prefetch, as in contribute), or copied now
+    const bool prefetched = c->prefetch.host == in && c->prefetch.bytes == n * ops->comp;
+    void *d_in;
+    if (prefetched) {
+        d_in = c->prefetch.dev;
+    } else {
+        void *&buf = c->in_sel ? c->d_in_alt : c->d_in;
+        size_t &cap = c->in_sel ? c->in_alt_cap : c->in_cap;
+        if ((rc = grow(buf, cap, n * ops->comp, err))) return rc;
+        d_in = buf;
+    }
+    c->prefetch = DeviceCtx::Prefetch{};
+    c->in_sel ^= 1;
     if (d_out_cap < n * ops->uncomp && c->buf_copying[sel]) {   // about to be reallocated: its last reader must be done
         HIP_TRY(hipEventSynchronize(c->bufev[sel]));
         c->buf_copying[sel] = false;
@@ -1017,12 +1030,24 @@ int run_verify_vector(DeviceCtx *c, int curve, int group, const GroupOps *ops, c
     if (c->buf_copying[sel]) HIP_TRY(hipStreamWaitEvent(c->stream, c->bufev[sel], 0));
     float ms = 0;
     HIP_TRY(hipEventRecord(c->ev[3], c->stream));
-    HIP_TRY(hipMemcpyAsync(c->d_in, in, n * ops->comp, hipMemcpyHostToDevice, c->stream));
+    if (prefetched) HIP_TRY(hipStreamWaitEvent(c->stream, c->pev[1], 0));
+    else HIP_TRY(hipMemcpyAsync(d_in, in, n * ops->comp, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
     HIP_TRY(hipEventRecord(c->ev[4], c->stream));
     const int nonzero = (check_output == PTAU_CHECK_ONLY_NON_ZERO || check_output == PTAU_CHECK_FULL) ? 1 : 0;
-    ops->decompress(c->stream, (const uint8_t *)c->d_in, (uint8_t *)d_out, n, nonzero, c->d_err);
+    ops->decompress(c->stream, (const uint8_t *)d_in, (uint8_t *)d_out, n, nonzero, c->d_err);
     HIP_TRY(hipEventRecord(c->ev[5], c->stream));
+    if (next_in && next_bytes) {   // the other input buffer is free: its last reader (the previous vector's square roots) is done
+        void *&nbuf = c->in_sel ? c->d_in_alt : c->d_in;
+        size_t &ncap = c->in_sel ? c->in_alt_cap : c->in_cap;
+        if ((rc = grow(nbuf, ncap, next_bytes, err))) return rc;
+        HIP_TRY(hipEventRecord(c->pev[0], c->copy_stream));
+        HIP_TRY(hipMemcpyAsync(nbuf, next_in, next_bytes, hipMemcpyHostToDevice, c->copy_stream));
+        HIP_TRY(hipEventRecord(c->pev[1], c->copy_stream));
+        c->prefetch.host = next_in;
+        c->prefetch.bytes = next_bytes;
+        c->prefetch.dev = nbuf;
+    }
     bool want_subgroup = subgroup_check_mode != PTAU_SUBGROUP_NO || check_output == PTAU_CHECK_ONLY_IN_GROUP ||
                          check_output == PTAU_CHECK_FULL;
     // SubgroupCheckMode::Batched, and Auto on more than 2^12 elements (setup-utils check_subgroup: BATCH_SIZE = 1 << 12,
@@ -1038,7 +1063,8 @@ int run_verify_vector(DeviceCtx *c, int curve, int group, const GroupOps *ops, c
     HIP_TRY(hipMemcpyAsync(&bits, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
+    if (prefetched) HIP_TRY(hipEventElapsedTime(&ms, c->pev[0], c->pev[1]));
+    else HIP_TRY(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
     c->timing.h2d_ms += ms;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[4], c->ev[5]));
     c->timing.kernel_ms += ms;
@@ -1846,6 +1872,7 @@ int verify_chunk_impl(const ptau_params *p, const uint8_t *challenge, size_t cha
     HIP_TRY(hipSetDevice(device));
     c->timing = ptau_timing{};
     c->pending.bytes = 0;   // a copy left pending by a call that failed must never land
+    c->prefetch = DeviceCtx::Prefetch{};
     const uint64_t n1 = sz.g1_chunk_size, n2 = sz.other_chunk_size;
     const uint8_t *pi = response + 64;
     uint8_t *po = new_challenge + 64;
@@ -1878,9 +1905,13 @@ int verify_chunk_impl(const ptau_params *p, const uint8_t *challenge, size_t cha
         auto &v = vec[k];
         vec_out[k] = po;
         uint8_t *pa = pairs.data() + (size_t)k * 2 * g2->uncomp, *pb = pa + g2->uncomp;
+        const uint8_t *nin = k < 3 && vec[k + 1].n ? pi + v.n * v.ops->comp : nullptr;
         if ((rc = run_verify_vector(c, p->curve, v.group, v.ops, pi, po, v.n, check_output, subgroup_check_mode,
                                     ratio_check ? seed : nullptr, sz.start, pa, pb, &nc_ready,
-                                    (size_t)(po + v.n * v.ops->uncomp - new_challenge), &track, err))) {
+                                    (size_t)(po + v.n * v.ops->uncomp - new_challenge), &track, err, nin,
+                                    nin ? vec[k + 1].n * vec[k + 1].ops->comp : 0))) {
+            if (c->prefetch.host) (void)hipStreamSynchronize(c->copy_stream);   // no copy from the caller's buffer stays in flight
+            c->prefetch = DeviceCtx::Prefetch{};
             hipStreamSynchronize(c->side_stream);   // never leave device work running past the caller's buffers
             return rc;
         }
