@@ -193,21 +193,35 @@ struct DeviceCtx {
     // serial latency, 3 ms on BLS12-377 G1, 13 ms on G2) runs on its own stream beside the NEXT vector's square roots and
     // membership tests; its results are collected by finish_msm_tail() before the next MSM touches the workspace
     hipStream_t tail_stream = nullptr;
-    hipEvent_t tev[4] = {};   // head start, head end (main stream), tail end (tail stream), buckets consumed (main stream)
-    void *bk_bytes = nullptr, *bk_pre = nullptr;   // membership-fused MSM: the bucket sums as uncompressed points, inversion scratch
-    size_t bk_bytes_cap = 0, bk_pre_cap = 0;
-    // the bucket tests run on the tail stream, beside whatever the main stream does next: their own K1 buffers and scalar
+    void *bk_pre = nullptr;   // membership-fused MSM: inversion scratch of the bucket normalisation (main stream, consumed at once)
+    size_t bk_pre_cap = 0;
+    // the bucket tests run on the tail stream, beside whatever the main stream does next: their own K1 buffers (tests of
+    // consecutive MSMs follow each other on the tail stream, so one set serves both slots)
     void *bk_scratch = nullptr, *bk_wtab = nullptr;
     size_t bk_scratch_cap = 0, bk_wtab_cap = 0;
-    uint32_t *bk_table = nullptr;
-    uint8_t *t_buf = nullptr;   // [pre 8 KB | results 4 KB | err 16 B]
     struct PendingTail {
         bool active = false;
         uint8_t *out_a = nullptr, *out_b = nullptr;
         int osz = 0;
         uint64_t points = 0;
         bool probe = false;   // a membership probe: its main-stream time is membership time, there are no sums to fetch
-    } tail;
+    };
+    // TWO sets of everything a tail owns — its buckets / parts / totals in the workspace (carved per slot), the bucket sums as
+    // points, the small result / error / scalar buffer, its events — so that the tail of vector k may still run while vector
+    // k + 1's bucket sums are queued (the G2 tail is 20 ms of one-wave kernels; the bucket tests of BW6-761 / the MNT twists
+    // are 10-60 ms): finish_msm_tail() collects slot s only before slot s is used again, two vectors later.
+    struct TailSlot {
+        hipEvent_t tev[4] = {};   // head start, head end (main stream), tail end (tail stream), buckets consumed (main stream)
+        void *bk_bytes = nullptr;   // the bucket sums as uncompressed points (read by the tests on the tail stream)
+        size_t bk_bytes_cap = 0;
+        uint32_t *bk_table = nullptr;
+        uint8_t *t_buf = nullptr;   // [pre 8 KB | results 4 KB | err 16 B | scalar of the bucket tests]
+        void *tws = nullptr;        // buckets | parts | totals of this slot's MSM (its own allocation: the other slot's may be in use)
+        size_t tws_cap = 0;
+        PendingTail tail;
+    } slots[2];
+    TailSlot *cur = &slots[0];   // the slot the next MSM / finish_msm_tail() works on
+    int slot_next = 0;
     // verify / combine: the D2H of a decompressed vector is queued on the copy stream and NOT waited for (CopyTrack); the next
     // writer of the same output buffer waits for it on the device
     hipEvent_t bufev[2] = {};
@@ -216,7 +230,7 @@ struct DeviceCtx {
     ptau_timing timing = {};
     double busy_ms = 0;   // kernel time since the library was loaded, every call on this device (under mu)
 };
-constexpr size_t TB_PRE = 0, TB_SMALL = 8192, TB_ERR = 12288, TB_TABLE = 12544, TB_SIZE = 16384;
+constexpr size_t TB_PRE = 0, TB_SMALL = 8192, TB_ERR = 12288, TB_TABLE = 12544, TB_SIZE = 16384;   // per tail slot
 DeviceCtx g_ctx[MAX_DEVICES];
 // second context per device (own stream and small buffers) for the lone beta_g2 element of a contribution: its update is
 // ONE thread's scalar multiplication (8 ms on BLS12-377, ~130 ms on MNT6 G2) and runs beside the four vectors.  Only used
@@ -240,9 +254,9 @@ int ensure_ctx(int device, DeviceCtx *&c, const Err &err, bool side = false) {
     std::lock_guard<std::mutex> init_lk(g_init_mu);
     if (c->ready) return PTAU_OK;
     hipStream_t st[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t evs[16] = {};
+    hipEvent_t evs[20] = {};
     void *bufs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    const size_t buf_sz[5] = {sizeof(uint32_t) * (1 + ptau::SCALAR_TABLE_ENTRIES) * 24, 256, 4096, 16384, TB_SIZE};
+    const size_t buf_sz[5] = {sizeof(uint32_t) * (1 + ptau::SCALAR_TABLE_ENTRIES) * 24, 256, 4096, 16384, 2 * TB_SIZE};
     hipError_t e = hipSuccess;
     const char *what = "";
     // Streams of one priority share a small pool of hardware queues (four by default), and two streams on one queue run
@@ -259,7 +273,7 @@ int ensure_ctx(int device, DeviceCtx *&c, const Err &err, bool side = false) {
         e = hipStreamCreateWithPriority(&st[i], hipStreamNonBlocking, std::min(std::max(prio[i], prio_greatest), prio_least));
         what = "hipStreamCreateWithPriority";
     }
-    for (int i = 0; i < 16 && e == hipSuccess; i++) { e = hipEventCreate(&evs[i]); what = "hipEventCreate"; }
+    for (int i = 0; i < 20 && e == hipSuccess; i++) { e = hipEventCreate(&evs[i]); what = "hipEventCreate"; }
     for (int i = 0; i < 5 && e == hipSuccess; i++) { e = hipMalloc(&bufs[i], buf_sz[i]); what = "hipMalloc"; }
     if (e != hipSuccess) {
         for (auto s : st) if (s) (void)hipStreamDestroy(s);
@@ -275,18 +289,22 @@ int ensure_ctx(int device, DeviceCtx *&c, const Err &err, bool side = false) {
     for (int i = 0; i < 6; i++) c->ev[i] = evs[i];
     c->cev[0] = evs[6];
     c->cev[1] = evs[7];
-    for (int i = 0; i < 4; i++) c->tev[i] = evs[8 + i];
+    for (int sl = 0; sl < 2; sl++) {
+        for (int i = 0; i < 4; i++) c->slots[sl].tev[i] = evs[(sl ? 16 : 8) + i];
+        c->slots[sl].t_buf = (uint8_t *)bufs[4] + sl * TB_SIZE;
+        c->slots[sl].bk_table = (uint32_t *)(c->slots[sl].t_buf + TB_TABLE);
+        c->slots[sl].tail = DeviceCtx::PendingTail{};
+    }
+    c->cur = &c->slots[0];
+    c->slot_next = 0;
     c->pev[0] = evs[12];
     c->pev[1] = evs[13];
     c->bufev[0] = evs[14];
     c->bufev[1] = evs[15];
-    c->t_buf = (uint8_t *)bufs[4];
-    c->bk_table = (uint32_t *)(c->t_buf + TB_TABLE);
     c->d_table = (uint32_t *)bufs[0];
     c->d_err = (int *)bufs[1];
     c->d_small = bufs[2];
     c->s_buf = (uint8_t *)bufs[3];
-    c->tail = DeviceCtx::PendingTail{};
     {
         hipDeviceProp_t prop;
         c->cus = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256;
@@ -572,9 +590,9 @@ int run_msm_bucket_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, i
     const bool only = fuse && fuse->only;
     const int test_cost = fuse ? std::max(1, ops->subgroup_cost_adds) : 0;
     const uint64_t resident_runs = (uint64_t)std::max(1, c->cus) * 512 / ops->msm_lanes_per_run;
-    if (c->tail.active) {   // left behind by a call that failed: its results are of no interest, its kernels must be done
-        HIP_TRY(hipStreamSynchronize(c->tail_stream));
-        c->tail.active = false;
+    if (c->cur->tail.active) {   // left behind by a call that failed: its results are of no interest, its kernels must be done
+        HIP_TRY(hipEventSynchronize(c->cur->tev[2]));
+        c->cur->tail.active = false;
     }
     const int isz = cin ? ops->comp : ops->uncomp, osz = cout ? ops->comp : ops->uncomp;
     const int nsum = out_b ? 2 : 1;
@@ -594,8 +612,8 @@ int run_msm_bucket_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, i
                  sz_parts = sz_buckets, sz_totals = al((nsum * (nslice + 1) + 8) * ops->jac_bytes),
                  sz_runs = al((wb_max + w_max * cap / ptau::MSM_RUN + 2) * ops->jac_bytes);   // <= one partial per bucket + one per run
     int rc;
-    if ((rc = grow(c->msm_ws, c->msm_cap, sz_aff + sz_dig + sz_sorted + sz_counts + 2 * sz_offsets + sz_buckets + sz_parts + sz_totals + sz_runs, err)))
-        return rc;
+    if ((rc = grow(c->msm_ws, c->msm_cap, sz_aff + sz_dig + sz_sorted + sz_counts + 2 * sz_offsets + sz_runs, err))) return rc;
+    if ((rc = grow(c->cur->tws, c->cur->tws_cap, sz_buckets + sz_parts + sz_totals, err))) return rc;
     if ((rc = grow(c->pre, c->pre_cap, 16 * ops->fe_bytes, err))) return rc;
     uint8_t *w8 = (uint8_t *)c->msm_ws;
     void *aff = w8;                                   w8 += sz_aff;
@@ -604,19 +622,19 @@ int run_msm_bucket_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, i
     uint32_t *counts = (uint32_t *)w8;                w8 += sz_counts;
     uint32_t *offsets = (uint32_t *)w8;               w8 += sz_offsets;
     uint32_t *run_offsets = (uint32_t *)w8;           w8 += sz_offsets;
-    uint8_t *buckets = w8;                            w8 += sz_buckets;
-    uint8_t *parts = w8;                              w8 += sz_parts;
-    uint8_t *totals = w8;                             w8 += sz_totals;   // [sum][slice] Jacobians, then the final [sum]
     uint8_t *runs = w8;                               // run partials of the accumulate pass
-    int *d_err = defer_tail ? (int *)(c->t_buf + TB_ERR) : c->d_err;
+    uint8_t *buckets = (uint8_t *)c->cur->tws;        // what the tail reads lives in the slot's own allocation
+    uint8_t *parts = buckets + sz_buckets;
+    uint8_t *totals = parts + sz_parts;               // [sum][slice] Jacobians, then the final [sum]
+    int *d_err = defer_tail ? (int *)(c->cur->t_buf + TB_ERR) : c->d_err;
     hipStream_t ts = c->stream;   // the stream of the tail kernels
     HIP_TRY(hipMemsetAsync(d_err, 0, sizeof(int), c->stream));
     if (fuse) {   // the fixed scalar of the bucket tests ([r] or [|t - 1|]), ahead of everything the tail stream will wait for
         const bool via_psi = ops->psi_check && use_endo_subgroup();
-        HIP_TRY(hipMemcpyAsync(c->bk_table, via_psi ? ops->psi_scalar : ops->group_order, sizeof(uint32_t) * ops->fr_limbs32,
+        HIP_TRY(hipMemcpyAsync(c->cur->bk_table, via_psi ? ops->psi_scalar : ops->group_order, sizeof(uint32_t) * ops->fr_limbs32,
                                hipMemcpyHostToDevice, c->stream));
     }
-    HIP_TRY(hipEventRecord(defer_tail ? c->tev[0] : c->ev[0], c->stream));
+    HIP_TRY(hipEventRecord(defer_tail ? c->cur->tev[0] : c->ev[0], c->stream));
     uint64_t li = 0;
     for (uint64_t off = 0; off < n || (n == 0 && li == 0); off += MSM_SLICE_POINTS, li++) {
         const uint64_t m = std::min(MSM_SLICE_POINTS, n - off);
@@ -640,23 +658,23 @@ int run_msm_bucket_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, i
         const bool last_slice = off + MSM_SLICE_POINTS >= n;
         if (fuse) {   // the bucket sums as points (before the reduction below reuses their memory), their tests on the tail stream
             const uint64_t nb = (uint64_t)nsum * wb;
-            if ((rc = grow(c->bk_bytes, c->bk_bytes_cap, nb * ops->uncomp, err))) return rc;
+            if ((rc = grow(c->cur->bk_bytes, c->cur->bk_bytes_cap, nb * ops->uncomp, err))) return rc;
             if ((rc = grow(c->bk_pre, c->bk_pre_cap, nb * ops->fe_bytes, err))) return rc;
-            ops->normalize(c->stream, buckets, c->bk_pre, (uint8_t *)c->bk_bytes, 0, nb, (nb + 3) / 4, 0, d_err);
-            HIP_TRY(hipEventRecord(c->tev[3], c->stream));
-            HIP_TRY(hipStreamWaitEvent(c->tail_stream, c->tev[3], 0));
-            if ((rc = enqueue_subgroup_kernels(c, fuse->curve, fuse->group, ops, (const uint8_t *)c->bk_bytes, 0, nb, err, /*side=*/true))) return rc;
+            ops->normalize(c->stream, buckets, c->bk_pre, (uint8_t *)c->cur->bk_bytes, 0, nb, (nb + 3) / 4, 0, d_err);
+            HIP_TRY(hipEventRecord(c->cur->tev[3], c->stream));
+            HIP_TRY(hipStreamWaitEvent(c->tail_stream, c->cur->tev[3], 0));
+            if ((rc = enqueue_subgroup_kernels(c, fuse->curve, fuse->group, ops, (const uint8_t *)c->cur->bk_bytes, 0, nb, err, /*side=*/true))) return rc;
             if (!last_slice) {   // the next slice reuses bk_bytes
-                HIP_TRY(hipEventRecord(c->tev[2], c->tail_stream));
-                HIP_TRY(hipStreamWaitEvent(c->stream, c->tev[2], 0));
+                HIP_TRY(hipEventRecord(c->cur->tev[2], c->tail_stream));
+                HIP_TRY(hipStreamWaitEvent(c->stream, c->cur->tev[2], 0));
             }
         }
         if (defer_tail && last_slice) {   // last slice: the main stream is done with this MSM here
             if (!fuse) {
-                HIP_TRY(hipEventRecord(c->tev[3], c->stream));
-                HIP_TRY(hipStreamWaitEvent(c->tail_stream, c->tev[3], 0));
+                HIP_TRY(hipEventRecord(c->cur->tev[3], c->stream));
+                HIP_TRY(hipStreamWaitEvent(c->tail_stream, c->cur->tev[3], 0));
             }
-            HIP_TRY(hipEventRecord(c->tev[1], c->stream));
+            HIP_TRY(hipEventRecord(c->cur->tev[1], c->stream));
             ts = c->tail_stream;
         }
         if (only) continue;
@@ -678,15 +696,15 @@ int run_msm_bucket_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, i
         for (int sidx = 0; sidx < nsum; sidx++)
             ops->reduce_sum(ts, totals + (size_t)sidx * nslice * ops->jac_bytes, fin + (size_t)sidx * ops->jac_bytes, li, 1);
     if (defer_tail) {
-        if (!only) ops->normalize(ts, fin, c->t_buf + TB_PRE, c->t_buf + TB_SMALL, cout, nsum, nsum, 0, d_err);
-        HIP_TRY(hipEventRecord(c->tev[2], ts));
+        if (!only) ops->normalize(ts, fin, c->cur->t_buf + TB_PRE, c->cur->t_buf + TB_SMALL, cout, nsum, nsum, 0, d_err);
+        HIP_TRY(hipEventRecord(c->cur->tev[2], ts));
         HIP_TRY(hipGetLastError());
-        c->tail.active = true;
-        c->tail.out_a = only ? nullptr : out_a;
-        c->tail.out_b = only ? nullptr : out_b;
-        c->tail.osz = osz;
-        c->tail.points = only ? 0 : n * nsum;
-        c->tail.probe = only;
+        c->cur->tail.active = true;
+        c->cur->tail.out_a = only ? nullptr : out_a;
+        c->cur->tail.out_b = only ? nullptr : out_b;
+        c->cur->tail.osz = osz;
+        c->cur->tail.points = only ? 0 : n * nsum;
+        c->cur->tail.probe = only;
         return PTAU_OK;
     }
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
@@ -766,26 +784,26 @@ int run_msm_naive_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, in
 // book the time.  kernel_ms gets the head (main stream) plus only what of the tail was NOT hidden: the part that ran past
 // `main_end` (the end of the next vector's kernels on the main stream), or all of it when nothing followed (main_end null).
 int finish_msm_tail(DeviceCtx *c, const Err &err, hipEvent_t *main_end) {
-    if (!c->tail.active) return PTAU_OK;
-    c->tail.active = false;
-    HIP_TRY(hipStreamSynchronize(c->tail_stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));   // the bucket membership kernels of the fused form write the same error word
+    if (!c->cur->tail.active) return PTAU_OK;
+    c->cur->tail.active = false;
+    HIP_TRY(hipEventSynchronize(c->cur->tev[2]));   // this slot's tail (the other slot's may still be running)
+    HIP_TRY(hipEventSynchronize(c->cur->tev[1]));   // ... and its head, for the timing below
     HIP_TRY(hipGetLastError());
     int bits = 0;
-    HIP_TRY(hipMemcpy(&bits, c->t_buf + TB_ERR, sizeof(int), hipMemcpyDeviceToHost));
-    if (c->tail.out_a) HIP_TRY(hipMemcpy(c->tail.out_a, c->t_buf + TB_SMALL, c->tail.osz, hipMemcpyDeviceToHost));
-    if (c->tail.out_b) HIP_TRY(hipMemcpy(c->tail.out_b, c->t_buf + TB_SMALL + c->tail.osz, c->tail.osz, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&bits, c->cur->t_buf + TB_ERR, sizeof(int), hipMemcpyDeviceToHost));
+    if (c->cur->tail.out_a) HIP_TRY(hipMemcpy(c->cur->tail.out_a, c->cur->t_buf + TB_SMALL, c->cur->tail.osz, hipMemcpyDeviceToHost));
+    if (c->cur->tail.out_b) HIP_TRY(hipMemcpy(c->cur->tail.out_b, c->cur->t_buf + TB_SMALL + c->cur->tail.osz, c->cur->tail.osz, hipMemcpyDeviceToHost));
     float head = 0, lat = 0, past = 0;
-    HIP_TRY(hipEventElapsedTime(&head, c->tev[0], c->tev[1]));
-    HIP_TRY(hipEventElapsedTime(&lat, c->tev[3], c->tev[2]));
+    HIP_TRY(hipEventElapsedTime(&head, c->cur->tev[0], c->cur->tev[1]));
+    HIP_TRY(hipEventElapsedTime(&lat, c->cur->tev[3], c->cur->tev[2]));
     // what of the tail ran past the main stream's own work: past the next vector's kernels, or past this MSM's head
-    if (hipEventElapsedTime(&past, main_end ? *main_end : c->tev[1], c->tev[2]) != hipSuccess) { (void)hipGetLastError(); past = lat; }
+    if (hipEventElapsedTime(&past, main_end ? *main_end : c->cur->tev[1], c->cur->tev[2]) != hipSuccess) { (void)hipGetLastError(); past = lat; }
     past = std::min(std::max(past, 0.0f), lat);
     c->timing.kernel_ms += head + past;
     c->busy_ms += head + past;
-    (c->tail.probe ? c->timing.subgroup_ms : c->timing.msm_ms) += head + past;
+    (c->cur->tail.probe ? c->timing.subgroup_ms : c->timing.msm_ms) += head + past;
     c->timing.msm_tail_ms += lat;
-    c->timing.points += c->tail.points;
+    c->timing.points += c->cur->tail.points;
     return errbits_to_code(bits, err);
 }
 
@@ -832,6 +850,7 @@ int enqueue_batched_subgroup_dev(DeviceCtx *c, int curve, int group, const Group
     }
     fclose(f);
     const MsmFuse fz{curve, group, true};
+    c->cur = &c->slots[0];   // (one tail at a time here: the caller collects it before the next)
     return run_msm_bucket_dev(c, ops, d_in, cin, n, ptau::ScalarSource{ptau::SCALAR_PRF, nullptr, seed[0], seed[1], 0}, nullptr, nullptr, 0,
                               err, true, &fz);
 }
@@ -866,13 +885,13 @@ int enqueue_subgroup_kernels(DeviceCtx *c, int curve, int group, const GroupOps 
                              const Err &err, bool side) {
     // side: the bucket tests of a membership-fused MSM — tail stream, the tail's error word, their own K1 buffers and scalar
     // (the main stream may be running the next vector's kernels, or K1 itself, at the same time); no timing events
-    int *const d_err = side ? (int *)(c->t_buf + TB_ERR) : c->d_err;
+    int *const d_err = side ? (int *)(c->cur->t_buf + TB_ERR) : c->d_err;
     hipStream_t const st = side ? c->tail_stream : c->stream;
     void *&scratch = side ? c->bk_scratch : c->scratch;
     size_t &scratch_cap = side ? c->bk_scratch_cap : c->scratch_cap;
     void *&wtab = side ? c->bk_wtab : c->wtab;
     size_t &wtab_cap = side ? c->bk_wtab_cap : c->wtab_cap;
-    uint32_t *const d_table = side ? c->bk_table : c->d_table;
+    uint32_t *const d_table = side ? c->cur->bk_table : c->d_table;
     const int isz = cin ? ops->comp : ops->uncomp;
     const uint64_t launch_cap =
         std::max<uint64_t>(256, std::min(MAX_LAUNCH_POINTS, MAX_WINDOW_TABLE_BYTES / (ptau::WINDOW_ENTRIES * ops->wtab_entry_bytes)));
@@ -1077,13 +1096,16 @@ int run_verify_vector(DeviceCtx *c, int curve, int group, const GroupOps *ops, c
         c->timing.subgroup_ms += ms;
     }
     c->timing.points += n;
-    // the previous vector's MSM tail ran beside the kernels just waited for
+    // This vector's MSM takes the tail slot that the MSM TWO vectors back used: that tail is collected now (it ran beside
+    // the previous vector's kernels and the ones just waited for); the previous vector's tail, on the other slot, goes on.
+    c->cur = &c->slots[c->slot_next];
     if ((rc = finish_msm_tail(c, err, want_subgroup ? &c->ev[1] : &c->ev[5]))) return rc;
     if ((rc = errbits_to_code(bits, err))) return rc;
     if (ratio_seed && n >= 2) {   // power_pairs on the vector while it is still resident in HBM; its tail is collected later
         const ptau::ScalarSource src{ptau::SCALAR_PRF, nullptr, ratio_seed[0], ratio_seed[1], index_base};
         const MsmFuse fz{curve, group};
         if ((rc = run_msm_dev(c, ops, (const uint8_t *)d_out, 0, n - 1, src, pair_a, pair_b, 0, err, /*defer_tail=*/true, fused ? &fz : nullptr))) return rc;
+        c->slot_next ^= 1;
     }
     // the decompressed vector goes home on the copy stream; nobody waits for it here
     return start_vector_copy(c, track, sel, d_out, out, n * ops->uncomp, ready, ready_mark, err);
@@ -1873,6 +1895,12 @@ int verify_chunk_impl(const ptau_params *p, const uint8_t *challenge, size_t cha
     c->timing = ptau_timing{};
     c->pending.bytes = 0;   // a copy left pending by a call that failed must never land
     c->prefetch = DeviceCtx::Prefetch{};
+    for (auto &sl : c->slots)   // MSM tails left behind by a call that failed: of no interest, but their kernels must be done
+        if (sl.tail.active) {
+            HIP_TRY(hipEventSynchronize(sl.tev[2]));
+            sl.tail.active = false;
+        }
+    c->slot_next = 0;
     const uint64_t n1 = sz.g1_chunk_size, n2 = sz.other_chunk_size;
     const uint8_t *pi = response + 64;
     uint8_t *po = new_challenge + 64;
@@ -1918,9 +1946,16 @@ int verify_chunk_impl(const ptau_params *p, const uint8_t *challenge, size_t cha
         pi += v.n * v.ops->comp;
         po += v.n * v.ops->uncomp;
     }
-    if ((rc = finish_msm_tail(c, err, nullptr))) {   // the last vector's MSM tail
-        hipStreamSynchronize(c->side_stream);
-        return rc;
+    {   // the MSM tails still out: the older one (it also had the last vector's kernels to hide behind), then the last vector's
+        DeviceCtx::TailSlot *older = &c->slots[c->slot_next], *newest = &c->slots[c->slot_next ^ 1];
+        c->cur = older;
+        rc = finish_msm_tail(c, err, newest->tail.active ? &newest->tev[1] : nullptr);
+        c->cur = newest;
+        if (!rc) rc = finish_msm_tail(c, err, nullptr);
+        if (rc) {
+            hipStreamSynchronize(c->side_stream);
+            return rc;
+        }
     }
     vec_out[4] = po;
     if ((rc = finish_single_side(c, err))) return rc;
