@@ -816,6 +816,15 @@ bool use_batched_subgroup() {
     return v;
 }
 
+// PTAU_TAIL_SLOTS=1: every MSM tail of a verification uses the same slot, i.e. is collected before the next MSM starts (A/B runs).
+bool use_two_tail_slots() {
+    static const bool v = [] {
+        const char *e = getenv("PTAU_TAIL_SLOTS");
+        return !(e && strcmp(e, "1") == 0);
+    }();
+    return v;
+}
+
 // PTAU_MSM_TAIL_OVERLAP=0: the verify path waits for every MSM as a whole (A/B runs).
 bool use_msm_tail_overlap() {
     static const bool v = [] {
@@ -1105,7 +1114,7 @@ int run_verify_vector(DeviceCtx *c, int curve, int group, const GroupOps *ops, c
         const ptau::ScalarSource src{ptau::SCALAR_PRF, nullptr, ratio_seed[0], ratio_seed[1], index_base};
         const MsmFuse fz{curve, group};
         if ((rc = run_msm_dev(c, ops, (const uint8_t *)d_out, 0, n - 1, src, pair_a, pair_b, 0, err, /*defer_tail=*/true, fused ? &fz : nullptr))) return rc;
-        c->slot_next ^= 1;
+        if (use_two_tail_slots()) c->slot_next ^= 1;
     }
     // the decompressed vector goes home on the copy stream; nobody waits for it here
     return start_vector_copy(c, track, sel, d_out, out, n * ops->uncomp, ready, ready_mark, err);
@@ -1947,9 +1956,12 @@ int verify_chunk_impl(const ptau_params *p, const uint8_t *challenge, size_t cha
         po += v.n * v.ops->uncomp;
     }
     {   // the MSM tails still out: the older one (it also had the last vector's kernels to hide behind), then the last vector's
+        // (tails follow each other on the one tail stream: what runs past the main stream's last kernel is counted once, with
+        // the newest; the older one ended before it)
         DeviceCtx::TailSlot *older = &c->slots[c->slot_next], *newest = &c->slots[c->slot_next ^ 1];
+        if (newest->tail.active) HIP_TRY(hipEventSynchronize(newest->tev[2]));
         c->cur = older;
-        rc = finish_msm_tail(c, err, newest->tail.active ? &newest->tev[1] : nullptr);
+        rc = finish_msm_tail(c, err, newest->tail.active ? &newest->tev[2] : nullptr);
         c->cur = newest;
         if (!rc) rc = finish_msm_tail(c, err, nullptr);
         if (rc) {
