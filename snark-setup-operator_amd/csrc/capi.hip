@@ -1548,7 +1548,6 @@ int ptau_contribute_file(const ptau_params *p, const char *challenge_path, const
         const size_t chl = ch.len;
         auto fut = std::async(std::launch::async, [chp, chl, &digest] { ptau_blake2b512(chp, chl, digest); });   // (critical path: not a background worker)
         ch.wait_pinned();
-        resp.wait_pinned();   // (BLAKE2b(challenge) is running: 0.36 s, the device needs half of that)
         rc = ptau_phase1_computation(p, chp, chl, out, resp.len, tau, alpha, beta, check_input, batch_exp_mode, device, errbuf, err_len);
         fut.get();
         if (rc) return rc;
@@ -1598,7 +1597,6 @@ int ptau_contribute_file_seeded(const ptau_params *p, const char *challenge_path
             return ptau_key_generation(curve, seed, seed_len, digest, t2, a2, b2, pk.data(), pk.size(), kmsg, sizeof(kmsg));
         });
         ch.wait_pinned();
-        resp.wait_pinned();   // (BLAKE2b(challenge) is running: 0.36 s, the device needs half of that)
         rc = ptau_phase1_computation(p, chp, chl, out, resp.len, tau, alpha, beta, check_input, batch_exp_mode, device, errbuf, err_len);
         const int krc = fut.get();
         if (rc) return rc;
