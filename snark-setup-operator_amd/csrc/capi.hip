@@ -1039,8 +1039,12 @@ int run_verify_vector(DeviceCtx *c, int curve, int group, const GroupOps *ops, c
     // the compressed input: copied while the previous vector's kernels ran (Prefetch, as in contribute), or copied now
     const bool prefetched = c->prefetch.host == in && c->prefetch.bytes == n * ops->comp;
     void *d_in;
+    float ms = 0;
     if (prefetched) {
         d_in = c->prefetch.dev;
+        HIP_TRY(hipEventSynchronize(c->pev[1]));   // queued a whole vector ago; its events are re-recorded for the next one below
+        HIP_TRY(hipEventElapsedTime(&ms, c->pev[0], c->pev[1]));
+        c->timing.h2d_ms += ms;
     } else {
         void *&buf = c->in_sel ? c->d_in_alt : c->d_in;
         size_t &cap = c->in_sel ? c->in_alt_cap : c->in_cap;
@@ -1056,10 +1060,8 @@ int run_verify_vector(DeviceCtx *c, int curve, int group, const GroupOps *ops, c
     if ((rc = grow(d_out, d_out_cap, n * ops->uncomp, err))) return rc;
     // the copy that last read this output buffer (two vectors ago, or another lane's) finishes before it is overwritten
     if (c->buf_copying[sel]) HIP_TRY(hipStreamWaitEvent(c->stream, c->bufev[sel], 0));
-    float ms = 0;
     HIP_TRY(hipEventRecord(c->ev[3], c->stream));
-    if (prefetched) HIP_TRY(hipStreamWaitEvent(c->stream, c->pev[1], 0));
-    else HIP_TRY(hipMemcpyAsync(d_in, in, n * ops->comp, hipMemcpyHostToDevice, c->stream));
+    if (!prefetched) HIP_TRY(hipMemcpyAsync(d_in, in, n * ops->comp, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
     HIP_TRY(hipEventRecord(c->ev[4], c->stream));
     const int nonzero = (check_output == PTAU_CHECK_ONLY_NON_ZERO || check_output == PTAU_CHECK_FULL) ? 1 : 0;
@@ -1091,9 +1093,10 @@ int run_verify_vector(DeviceCtx *c, int curve, int group, const GroupOps *ops, c
     HIP_TRY(hipMemcpyAsync(&bits, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipGetLastError());
-    if (prefetched) HIP_TRY(hipEventElapsedTime(&ms, c->pev[0], c->pev[1]));
-    else HIP_TRY(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
-    c->timing.h2d_ms += ms;
+    if (!prefetched) {
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
+        c->timing.h2d_ms += ms;
+    }
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[4], c->ev[5]));
     c->timing.kernel_ms += ms;
     c->busy_ms += ms;
