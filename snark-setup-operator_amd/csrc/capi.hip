@@ -658,12 +658,18 @@ int run_msm_bucket_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, i
         const bool last_slice = off + MSM_SLICE_POINTS >= n;
         if (fuse) {   // the bucket sums as points (before the reduction below reuses their memory), their tests on the tail stream
             const uint64_t nb = (uint64_t)nsum * wb;
-            if ((rc = grow(c->cur->bk_bytes, c->cur->bk_bytes_cap, nb * ops->uncomp, err))) return rc;
-            if ((rc = grow(c->bk_pre, c->bk_pre_cap, nb * ops->fe_bytes, err))) return rc;
-            ops->normalize(c->stream, buckets, c->bk_pre, (uint8_t *)c->cur->bk_bytes, 0, nb, (nb + 3) / 4, 0, d_err);
+            // BLS12-377 G1: the test takes the Jacobian sums as they are (Z ignored: kernels_impl.hpp endo_membership_lazy) — the
+            // tail stream runs it BEFORE the reduction kernels that reuse the buckets' memory; other groups: normalise first
+            const bool jac_test = ops->endo_subgroup_jac && use_endo_subgroup();
+            if (!jac_test) {
+                if ((rc = grow(c->cur->bk_bytes, c->cur->bk_bytes_cap, nb * ops->uncomp, err))) return rc;
+                if ((rc = grow(c->bk_pre, c->bk_pre_cap, nb * ops->fe_bytes, err))) return rc;
+                ops->normalize(c->stream, buckets, c->bk_pre, (uint8_t *)c->cur->bk_bytes, 0, nb, (nb + 3) / 4, 0, d_err);
+            }
             HIP_TRY(hipEventRecord(c->cur->tev[3], c->stream));
             HIP_TRY(hipStreamWaitEvent(c->tail_stream, c->cur->tev[3], 0));
-            if ((rc = enqueue_subgroup_kernels(c, fuse->curve, fuse->group, ops, (const uint8_t *)c->cur->bk_bytes, 0, nb, err, /*side=*/true))) return rc;
+            if (jac_test) ops->endo_subgroup_jac(c->tail_stream, buckets, nb, d_err);
+            else if ((rc = enqueue_subgroup_kernels(c, fuse->curve, fuse->group, ops, (const uint8_t *)c->cur->bk_bytes, 0, nb, err, /*side=*/true))) return rc;
             if (!last_slice) {   // the next slice reuses bk_bytes
                 HIP_TRY(hipEventRecord(c->cur->tev[2], c->tail_stream));
                 HIP_TRY(hipStreamWaitEvent(c->stream, c->cur->tev[2], 0));

@@ -1361,6 +1361,58 @@ on_curve_kernel(const uint8_t *__restrict__ in, uint64_t n, int *__restrict__ er
 // 1/4 (G2) of the doublings — eprint 2021/1130 (the test ark-bls12-377 0.4's is_in_correct_subgroup_assuming_on_curve
 // applies):   G1: (C0 x, y) == -[X^2] P        G2: psi(P) = (C0 conj(x), C1 conj(y)) == [X] P.
 // X = 0x8508c00000000001 has 7 set bits: plain MSB-first double-and-add, wave-uniform control flow, no table.
+// The endomorphism membership test in the carry-free field, on (x, y) given in the reduced field.  For G1 (ENDO_KIND 1) the pair
+// may also be the X, Y of a JACOBIAN point (X, Y, Z), Z != 0, with Z simply ignored: (X, Y) is an affine point of the isomorphic
+// curve y^2 = x^3 + b Z^6, the isomorphism (x, y) -> (x / Z^2, y / Z^3) is defined over Fq and commutes with the endomorphism
+// (beta x, y) and with scalar multiplication, and neither the doubling nor the mixed addition involves b — the verdict is the
+// one of the point itself (endo_subgroup_jac_kernel: the bucket sums of the membership-fused MSM need no normalisation).
+template <class G>
+PTAU_HD int endo_membership_lazy(const typename G::F &x29, const typename G::F &y29) {
+    using Cfg = typename G::J::CfgT;
+    constexpr uint64_t X = Cfg::ENDO_X;
+    const auto px = LazyOf<G>::to_lazy(x29), py = LazyOf<G>::to_lazy(y29);
+    // the same test in the carry-free field (fpz.hpp).  G1's second multiplication by X starts from a Jacobian point
+    // (Xb, Yb, Zb): that is the affine point (Xb, Yb) of the isomorphic curve y^2 = x^3 + b Zb^6, neither the doubling nor
+    // the mixed addition involves b, so the chain runs there with mixed additions and Z maps back as Z Zb.
+    using L = LazyOf<G>;
+    using K = typename L::K;
+    using Acc = typename L::Acc;
+    const typename L::AY pya = py;
+    Acc t = {px, py, K::one()};
+    for (int b = 62; b >= 0; b--) {   // bit 63 of X is set
+        t = Acc::dbl(t);
+        if ((X >> b) & 1ull) t = Acc::add_mixed(t, px, pya);
+    }
+    if (t.is_inf()) return ERRBIT_NOT_IN_SUBGROUP;
+    typename L::LZ::template E<1, 1> c0, c1;
+#pragma unroll
+    for (int j = 0; j < L::N; j++) { c0.l[j] = Cfg::ENDO_C0Z[j]; c1.l[j] = Cfg::ENDO_C1Z[j]; }
+    if constexpr (Cfg::ENDO_KIND == 1) {
+        const auto zb = t.Zc;
+        const auto bx = K::vreduce(t.X), by = K::vreduce(t.Y);   // below 3p, as add_mixed takes them
+        const typename L::AX bxa = bx;
+        const typename L::AY bya = by;
+        Acc u = {bx, by, K::one()};
+        for (int b = 62; b >= 0; b--) {
+            u = Acc::dbl(u);
+            if ((X >> b) & 1ull) u = Acc::add_mixed(u, bxa, bya);
+        }
+        if (u.is_inf()) return ERRBIT_NOT_IN_SUBGROUP;
+        const auto zf = K::mul(u.Zc, zb);
+        const auto zz = K::sqr(zf);
+        const auto ex = K::mul(px, c0);
+        const bool okx = K::is_zero(K::norm(K::sub(u.X, K::mul(ex, zz))));
+        const bool oky = K::is_zero(K::norm(K::add(u.Y, K::mul(py, K::mul(zz, zf)))));   // Y == -y Z^3
+        return okx && oky ? 0 : ERRBIT_NOT_IN_SUBGROUP;
+    } else {
+        const auto ex = K::mul_base(K::conj(px), c0), ey = K::mul_base(K::conj(py), c1);
+        const auto zz = K::sqr(t.Zc);
+        const bool okx = K::is_zero(K::norm(K::sub(t.X, K::mul(ex, zz))));
+        const bool oky = K::is_zero(K::norm(K::sub(t.Y, K::mul(ey, K::mul(zz, t.Zc)))));
+        return okx && oky ? 0 : ERRBIT_NOT_IN_SUBGROUP;
+    }
+}
+
 template <class G>
 PTAU_HD int endo_subgroup_thread(const uint8_t *in, int compressed_in, uint64_t i) {
     using F = typename G::F;
@@ -1375,49 +1427,7 @@ PTAU_HD int endo_subgroup_thread(const uint8_t *in, int compressed_in, uint64_t 
     if (p.inf) return 0;
     if (!compressed_in && !(F::sqr(p.y) == curve_rhs<F, Cfg>(p.x))) return ERRBIT_NOT_ON_CURVE;
     constexpr uint64_t X = Cfg::ENDO_X;
-    if constexpr (G::LAZY_LOOP) {
-        // the same test in the carry-free field (fpz.hpp).  G1's second multiplication by X starts from a Jacobian point
-        // (Xb, Yb, Zb): that is the affine point (Xb, Yb) of the isomorphic curve y^2 = x^3 + b Zb^6, neither the doubling nor
-        // the mixed addition involves b, so the chain runs there with mixed additions and Z maps back as Z Zb.
-        using L = LazyOf<G>;
-        using K = typename L::K;
-        using Acc = typename L::Acc;
-        const auto px = L::to_lazy(p.x), py = L::to_lazy(p.y);
-        const typename L::AY pya = py;
-        Acc t = {px, py, K::one()};
-        for (int b = 62; b >= 0; b--) {   // bit 63 of X is set
-            t = Acc::dbl(t);
-            if ((X >> b) & 1ull) t = Acc::add_mixed(t, px, pya);
-        }
-        if (t.is_inf()) return ERRBIT_NOT_IN_SUBGROUP;
-        typename L::LZ::template E<1, 1> c0, c1;
-#pragma unroll
-        for (int j = 0; j < L::N; j++) { c0.l[j] = Cfg::ENDO_C0Z[j]; c1.l[j] = Cfg::ENDO_C1Z[j]; }
-        if constexpr (Cfg::ENDO_KIND == 1) {
-            const auto zb = t.Zc;
-            const auto bx = K::vreduce(t.X), by = K::vreduce(t.Y);   // below 3p, as add_mixed takes them
-            const typename L::AX bxa = bx;
-            const typename L::AY bya = by;
-            Acc u = {bx, by, K::one()};
-            for (int b = 62; b >= 0; b--) {
-                u = Acc::dbl(u);
-                if ((X >> b) & 1ull) u = Acc::add_mixed(u, bxa, bya);
-            }
-            if (u.is_inf()) return ERRBIT_NOT_IN_SUBGROUP;
-            const auto zf = K::mul(u.Zc, zb);
-            const auto zz = K::sqr(zf);
-            const auto ex = K::mul(px, c0);
-            const bool okx = K::is_zero(K::norm(K::sub(u.X, K::mul(ex, zz))));
-            const bool oky = K::is_zero(K::norm(K::add(u.Y, K::mul(py, K::mul(zz, zf)))));   // Y == -y Z^3
-            return okx && oky ? 0 : ERRBIT_NOT_IN_SUBGROUP;
-        } else {
-            const auto ex = K::mul_base(K::conj(px), c0), ey = K::mul_base(K::conj(py), c1);
-            const auto zz = K::sqr(t.Zc);
-            const bool okx = K::is_zero(K::norm(K::sub(t.X, K::mul(ex, zz))));
-            const bool oky = K::is_zero(K::norm(K::sub(t.Y, K::mul(ey, K::mul(zz, t.Zc)))));
-            return okx && oky ? 0 : ERRBIT_NOT_IN_SUBGROUP;
-        }
-    }
+    if constexpr (G::LAZY_LOOP) return endo_membership_lazy<G>(p.x, p.y);
     J t = J::from_affine(p);
     for (int b = 62; b >= 0; b--) {   // bit 63 of X is set
         t = J::dbl(t);
@@ -1450,6 +1460,20 @@ endo_subgroup_kernel(const uint8_t *__restrict__ in, uint64_t n, int *__restrict
     uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G::LPP;
     if (i >= n) return;
     int bad = endo_subgroup_thread<G>(in, CIN, i);
+    if (bad) atomicOr(err, bad);
+}
+
+// The same test on JACOBIAN points (X, Y, Z) with Z ignored (endo_membership_lazy's comment): the bucket sums of the
+// membership-fused MSM, straight from the combine pass.  G1 with a carry-free twin only (on G2 the Frobenius inside psi does not
+// commute with a scaling by Z in Fq2).
+template <class G>
+__global__ void __launch_bounds__(256, G::MIN_WAVES)
+endo_subgroup_jac_kernel(const typename G::J *__restrict__ pts, uint64_t n, int *__restrict__ err) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const typename G::J p = pts[i];
+    if (p.Z.is_zero()) return;   // an empty bucket
+    const int bad = endo_membership_lazy<G>(p.X, p.Y);
     if (bad) atomicOr(err, bad);
 }
 
@@ -1737,6 +1761,8 @@ struct GroupOps {
     void (*expect_infinity)(hipStream_t, const void *scratch, uint64_t n, int *err);
     // endomorphism membership test incl. the on-curve test of uncompressed input; NULL where the group has none
     void (*endo_subgroup)(hipStream_t, const uint8_t *in, int cin, uint64_t n, int *err);
+    // ... on Jacobian points in the group's standard layout, Z ignored (BLS12-377 G1: bucket sums need no normalisation); or NULL
+    void (*endo_subgroup_jac)(hipStream_t, const void *jac, uint64_t n, int *err);
     // membership through K1's GLV loop with the fixed pair (a, b), [a]P + [b]phi(P) == O (SCALAR_SUBGROUP_ENDO): BW6-761
     bool subgroup_via_glv;
     // the membership test costs a small fraction of what the endomorphism multiplication saves over the plain one (BLS12-377
@@ -1907,6 +1933,12 @@ struct Launch {
         if (!n) return;
         hipLaunchKernelGGL(expect_infinity_kernel<G>, grid(n), dim3(256), 0, s, (const typename G::J *)scratch, n, err);
     }
+    static void endo_subgroup_jac(hipStream_t s, const void *jac, uint64_t n, int *err) {
+        if constexpr (G::J::CfgT::ENDO_KIND == 1 && G::LAZY_LOOP && G::LANE_MODE == LANES_ONE) {
+            if (!n) return;
+            hipLaunchKernelGGL(endo_subgroup_jac_kernel<G>, grid(n), dim3(256), 0, s, (const typename G::J *)jac, n, err);
+        }
+    }
     static void endo_subgroup(hipStream_t s, const uint8_t *in, int cin, uint64_t n, int *err) {
         if constexpr (G::J::CfgT::ENDO_KIND != 0) {
             if (!n) return;
@@ -1968,6 +2000,8 @@ struct Launch {
         o.normalize = normalize;
         o.expect_infinity = expect_infinity;
         o.endo_subgroup = G::J::CfgT::ENDO_KIND != 0 ? endo_subgroup : nullptr;
+        o.endo_subgroup_jac = nullptr;
+        if constexpr (G::J::CfgT::ENDO_KIND == 1 && G::LAZY_LOOP && G::LANE_MODE == LANES_ONE) o.endo_subgroup_jac = endo_subgroup_jac;
         o.subgroup_via_glv = G::J::CfgT::GLV_KIND == 2;
         o.membership_cheap = G::J::CfgT::ENDO_KIND == 2 && Fr::N == 8;
         o.has_endo_mul = G::J::CfgT::GLV_KIND != 0 || (G::J::CfgT::ENDO_KIND == 2 && Fr::N == 8);
