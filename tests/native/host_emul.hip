@@ -12,6 +12,9 @@
 //        msmplan: no input; <n> = points, <start> = bucket test cost (0 = the plain plan for 127-bit scalars), <cin> = resident runs
 //               in thousands; stdout = text "c W B bits"
 //        subgroup : stdin = n points; stdout = n bytes of error bits (0 = in the prime-order subgroup)
+//        subgroupjac : BLS12-377 G1 only.  The same points, each scaled to a Jacobian representative (X, Y, Z) = (x z^2, y z^3, z)
+//               with z = index + 2, through the membership test that IGNORES Z (endo_membership_lazy; the bucket sums of the
+//               membership-fused MSM); stdout = n bytes of error bits
 //        msm  : stdin = n points (uncompressed) then n x Fr::N u32 scalar limbs; <start> = window bits c (0 = the
 //               library's own plan), <cout> = 1 adds the shifted sum (needs n + 1 points); stdout = 1 or 2 points
 #include <cstdio>
@@ -189,6 +192,22 @@ static int run(const std::string &op, uint64_t n, uint64_t start, int cin, int c
         std::vector<typename G::F> pre(nsum);
         out.resize(nsum * G::UNCOMP);
         for (int t = 0; t < nsum; t++) bad |= normalize_thread<G>(fin.data(), pre.data(), out.data(), 0, nsum, nsum, t, 0);
+    } else if (op == "subgroupjac") {
+        out.resize(n);
+        if constexpr (G::J::CfgT::ENDO_KIND == 1 && G::LAZY_LOOP && G::LANE_MODE == LANES_ONE) {
+            using F = typename G::F;
+            for (uint64_t i = 0; i < n; i++) {
+                typename G::A p;
+                int b = read_point_any<G>(in.data(), cin, i, p);
+                if (b || p.inf) { out[i] = (uint8_t)b; continue; }
+                const F z = F::mul_small(F::one(), (int)(i % 1000) + 2), z2 = F::sqr(z);
+                out[i] = (uint8_t)endo_membership_lazy<G>(F::mul(p.x, z2), F::mul(p.y, F::mul(z2, z)));
+            }
+        } else {
+            return 4;
+        }
+        fwrite(out.data(), 1, out.size(), stdout);
+        return 0;
     } else if (op == "subgroup") {
         // endomorphism membership test (K3'), one result byte (error bits) per point
         out.resize(n);
