@@ -302,7 +302,8 @@ int ptau_transform_ratios_file(const ptau_params *full, const char *combined_pat
  * (overlapping by one element), slice k is reduced by power_pairs on devices[k] on its own host thread under ONE rho stream
  * (one seed, coefficients keyed by the global index), the n_devices partial pairs per vector are summed and the five
  * pairing checks run once, on devices[0].  Same accept / reject set as ptau_transform_ratios.  check_input: each slice is
- * membership-tested on its device. */
+ * membership-tested on its device.  An ordinal may be listed more than once (its slices queue on that device's lock):
+ * {0, 0, 0} cuts every vector into three slices on one GPU. */
 int ptau_transform_ratios_devices(const ptau_params *full, const uint8_t *combined, size_t combined_len, int check_input,
                                   const int *devices, int n_devices, char *err, size_t err_len);
 int ptau_transform_ratios_file_devices(const ptau_params *full, const char *combined_path, int check_input,
@@ -355,7 +356,11 @@ int ptau_contribute_file_seeded(const ptau_params *p, const char *challenge_path
  * GPU-busy fraction over a wall-clock interval (several in-process lanes).  < 0 on a bad ordinal. */
 double ptau_device_busy_ms(int device);
 
-/* Timings of the most recent compute call on `device`. */
+/* Timings and check counts of the most recent compute call THE CALLING THREAD made on `device` (all zero if it made none).
+ * The record belongs to the call, not to the device: several in-process lanes (threads) may share a GPU, and each reads its
+ * own call's numbers — in particular the `ratio_checks == 0` ("power ratios NOT checked here") signal of a verification —
+ * whatever the other lanes did meanwhile.  Read it on the thread that made the call (the operator runs every phase1_cli call
+ * inside one spawn_quiet closure, src/bin/contribute.rs:809-856, 966-1025: read it in that closure). */
 int ptau_last_timing(int device, ptau_timing *out);
 
 #ifdef __cplusplus

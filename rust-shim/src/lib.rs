@@ -64,6 +64,17 @@ pub struct PtauTiming {
     pub msm_tail_ms: f64,
 }
 
+/// What one `transform_pok_and_correctness` call checked (from that call's own `PtauTiming`).
+#[derive(Clone, Copy, Debug)]
+pub struct VerifyReport {
+    /// power-ratio (same-ratio pairing) checks run; 0 with `ratio_check = true` = NOT performed on this chunk
+    pub ratio_checks: u32,
+    /// proofs of knowledge + chunk-0 before/after checks run
+    pub pok_checks: u32,
+    /// device time of the call's kernels, ms
+    pub device_ms: f64,
+}
+
 pub const PTAU_BATCH_EXP_INPUT_IN_SUBGROUP: c_int = 0x100;
 
 extern "C" {
@@ -149,8 +160,11 @@ pub mod phase1_cli {
     use super::*;
 
     /// `phase1_cli::contribute` (`contribute.rs:811-823`) — `rng` is `derive_rng_from_seed(seed)`.
-    /// `input_in_subgroup`: the challenge came from this ceremony's verifier (it always does in the operator:
-    /// `new_challenge` or a verified response), which enables the endomorphism-accelerated update.
+    /// `input_in_subgroup`: pass `false` at the operator's call sites.  A downloaded challenge is data of unknown origin
+    /// to a contributor; the reference runs `CheckForCorrectness::No` on it and returns `[k]P` for whatever bytes arrived,
+    /// and with `false` so does this call (`BatchExpMode::Auto` probes the vectors itself and takes the endomorphism
+    /// kernels only when the probe passes).  `true` is legitimate ONLY for a caller that ran `CheckForCorrectness::Full`
+    /// on the same bytes itself: on a point outside the prime-order subgroup the asserted path returns a different point.
     pub fn contribute(challenge_filename: &str, challenge_hash_filename: &str, response_filename: &str, response_hash_filename: &str,
                       check_input_correctness: CheckForCorrectness, batch_exp_mode: BatchExpMode, parameters: &PtauParams,
                       seed: &[u8], input_in_subgroup: bool, device: i32) {
@@ -179,10 +193,14 @@ pub mod phase1_cli {
     /// `phase1_cli::transform_pok_and_correctness` (`contribute.rs:968-986`), the reference's eleven arguments; `g2_s`:
     /// `None` (derived by the library) or arkworks' three `compute_g2_s` points, uncompressed; `tau_g2_check`: `None`, or
     /// `tauG2[0] | tauG2[1]` (uncompressed) of the same contribution so that `ratio_check` covers a tauG1-only chunk.
+    /// Returns what THIS call checked (`ptau_last_timing` is per calling thread, so the record is this call's whatever other
+    /// lanes did on the same GPU meanwhile): `ratio_checks == 0` under `ratio_check = true` means the chunk holds no tauG2
+    /// pair and no `tau_g2_check` was given — its tauG1 power ratios are then left to `transform_ratios` on the combined
+    /// accumulator (`control.rs:587-591`).  A verifier that must not accept such a chunk unchecked asserts on it.
     pub fn transform_pok_and_correctness(challenge_filename: &str, challenge_hash_filename: &str, check_input_correctness: CheckForCorrectness,
                                          response_filename: &str, response_hash_filename: &str, check_output_correctness: CheckForCorrectness,
                                          new_challenge_filename: &str, new_challenge_hash_filename: &str, subgroup_check_mode: SubgroupCheckMode,
-                                         ratio_check: bool, parameters: &PtauParams, g2_s: Option<&[u8]>, tau_g2_check: Option<&[u8]>, device: i32) {
+                                         ratio_check: bool, parameters: &PtauParams, g2_s: Option<&[u8]>, tau_g2_check: Option<&[u8]>, device: i32) -> VerifyReport {
         let mut err = [0 as c_char; 256];
         let (c, ch, r, rh, n, nh) = (cpath(challenge_filename), cpath(challenge_hash_filename), cpath(response_filename),
                                      cpath(response_hash_filename), cpath(new_challenge_filename), cpath(new_challenge_hash_filename));
@@ -192,6 +210,9 @@ pub mod phase1_cli {
                                                                   tau_g2_check.map_or(std::ptr::null(), |s| s.as_ptr()), device,
                                                                   err.as_mut_ptr(), err.len()) };
         check("phase1_cli::transform_pok_and_correctness", rc, &err);
+        let mut t: PtauTiming = unsafe { std::mem::zeroed() };
+        unsafe { ptau_last_timing(device, &mut t) };   // same thread as the call above: this call's record
+        VerifyReport { ratio_checks: t.ratio_checks, pok_checks: t.pok_checks, device_ms: t.kernel_ms }
     }
 
     /// `phase1_cli::new_challenge` (`new_setup.rs:105-109`).  MNT4-753 / MNT6-753: use [`new_challenge_with_generators`].

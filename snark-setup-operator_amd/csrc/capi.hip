@@ -323,6 +323,63 @@ int grow(void *&p, size_t &cap, size_t need, const Err &err) {
     return PTAU_OK;
 }
 
+// Start of every device section (caller holds c->mu): select the device and forget whatever an earlier call — possibly one
+// that FAILED half way — left in the per-device state.  A deferred copy must never land, a prefetch record must not match a
+// new caller's pointer, and an MSM tail queued by a failed call is of no interest but its kernels must be done before its
+// slot (buffers, result pointers into that call's dead frame) is used again: finish_msm_tail() on a stale active slot would
+// copy results to freed host memory.
+int begin_device_section(DeviceCtx *c, int device, const Err &err) {
+    HIP_TRY(hipSetDevice(device));
+    c->timing = ptau_timing{};
+    c->pending.bytes = 0;
+    if (c->prefetch.host) (void)hipStreamSynchronize(c->copy_stream);
+    c->prefetch = DeviceCtx::Prefetch{};
+    for (auto &sl : c->slots)
+        if (sl.tail.active) {
+            HIP_TRY(hipEventSynchronize(sl.tev[2]));
+            sl.tail = DeviceCtx::PendingTail{};
+        }
+    c->slot_next = 0;
+    c->cur = &c->slots[0];
+    return PTAU_OK;
+}
+
+// Per-call timings belong to the CALL, not to the device: several in-process lanes share a device, each resets c->timing
+// when it takes the lock, and a verification finishes its counters (ratio_checks, pok_checks, d2h_ms) after it has released
+// the lock.  So every entry point publishes its own record to the calling thread when it ends (ptau_last_timing reads the
+// calling thread's record); a call that goes on after its device section detaches a private copy first.
+thread_local ptau_timing tl_timing[MAX_DEVICES];
+struct CallTiming {   // declare AFTER the lock guard: the destructor then reads c->timing while the lock is still held
+    DeviceCtx *c;
+    int device;
+    bool detached = false;
+    ptau_timing mine = {};
+    void detach() { mine = c->timing; detached = true; }   // under the lock, just before it is released
+    ~CallTiming() { tl_timing[device] = detached ? mine : c->timing; }
+};
+
+// The output staging buffer `sel` (d_out / d_out_alt), at least `need` bytes.  A verification queues the device-to-host copy
+// of a decompressed vector on the copy stream and does NOT wait for it inside its device section (CopyTrack), so such a copy
+// may still be reading the buffer when the NEXT holder of the device lock — any entry point, another lane — wants to write
+// it: every writer orders its stream behind that copy (on the device), or waits on the host when the buffer is about to be
+// reallocated.
+int claim_out_buffer(DeviceCtx *c, int sel, size_t need, void *&buf, const Err &err) {
+    void *&d = sel ? c->d_out_alt : c->d_out;
+    size_t &cap = sel ? c->out_alt_cap : c->out_cap;
+    if (c->buf_copying[sel]) {
+        if (cap < need) {
+            HIP_TRY(hipEventSynchronize(c->bufev[sel]));
+            c->buf_copying[sel] = false;
+        } else {
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->bufev[sel], 0));
+        }
+    }
+    int rc = grow(d, cap, need, err);
+    if (rc) return rc;
+    buf = d;
+    return PTAU_OK;
+}
+
 int errbits_to_code(int bits, const Err &err) {
     if (!bits) return PTAU_OK;
     if (bits & ptau::ERRBIT_NONCANONICAL) return err.fail(PTAU_E_POINT, "non-canonical field element in input");
@@ -445,10 +502,10 @@ int run_apply_powers_host(DeviceCtx *c, int curve, int group, const GroupOps *op
     const size_t isz = cin ? ops->comp : ops->uncomp, osz = cout ? ops->comp : ops->uncomp;
     if (!n) return PTAU_OK;
     int rc;
-    void *&d_out = c->out_sel ? c->d_out_alt : c->d_out;
-    size_t &d_out_cap = c->out_sel ? c->out_alt_cap : c->out_cap;
+    void *d_out = nullptr;
+    const int osel = c->out_sel;
     c->out_sel ^= 1;
-    if ((rc = grow(d_out, d_out_cap, n * osz, err))) return rc;
+    if ((rc = claim_out_buffer(c, osel, n * osz, d_out, err))) return rc;   // (behind another lane's copy out of it, if any)
     float ms = 0;
     void *d_in;
     if (c->prefetch.host == in && c->prefetch.bytes == n * isz) {   // copied while the previous vector's kernels ran
@@ -562,7 +619,8 @@ uint32_t msm_run_length(const DeviceCtx *c, const GroupOps *ops, uint64_t m, con
     static const uint32_t forced = [] {
         const char *e = getenv("PTAU_MSM_RUN");
         const long v = e ? atol(e) : 0;
-        return (uint32_t)(v >= 8 && v <= 4096 ? v : 0);
+        // clamped to what the workspace (sz_runs: one partial per MSM_RUN entries) and msm_plan's resident-lane model assume
+        return (uint32_t)(v > 0 ? std::min<long>(ptau::MSM_RUN_MAX, std::max<long>(ptau::MSM_RUN, v)) : 0);
     }();
     if (forced) return forced;
     const uint64_t resident = (uint64_t)std::max(1, c->cus) * 512 / ops->msm_lanes_per_run;   // two waves per SIMD (199-256 VGPRs)
@@ -989,8 +1047,13 @@ struct CopyTrack {
         std::atomic<size_t> *ready;
         size_t mark;
         std::chrono::steady_clock::time_point t0;
+        unsigned delay_us;   // test hook (PTAU_TEST_COPY_DELAY_MS): holds the copy back so that it outlives the device section
     };
-    static void on_start(void *u) { ((Node *)u)->t0 = std::chrono::steady_clock::now(); }
+    static void on_start(void *u) {
+        Node *n = (Node *)u;
+        if (n->delay_us) usleep(n->delay_us);
+        n->t0 = std::chrono::steady_clock::now();
+    }
     static void on_end(void *u) {
         Node *n = (Node *)u;
         n->t->d2h_ns.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - n->t0).count());
@@ -1013,7 +1076,11 @@ struct CopyTrack {
 };
 int start_vector_copy(DeviceCtx *c, CopyTrack *track, int sel, const void *src, uint8_t *dst, size_t bytes, std::atomic<size_t> *ready,
                       size_t mark, const Err &err) {
-    CopyTrack::Node *node = new CopyTrack::Node{track, ready, mark, {}};
+    // PTAU_TEST_COPY_DELAY_MS=<ms> (tests only, read per copy): a host callback ahead of the copy sleeps that long, so the copy
+    // is certainly still queued when this lane releases the device — the next lane's writers must order themselves behind it
+    const char *dly = getenv("PTAU_TEST_COPY_DELAY_MS");
+    const long dly_ms = dly ? atol(dly) : 0;
+    CopyTrack::Node *node = new CopyTrack::Node{track, ready, mark, {}, (unsigned)(dly_ms > 0 && dly_ms <= 2000 ? dly_ms * 1000 : 0)};
     track->stream = c->copy_stream;
     track->outstanding.fetch_add(1, std::memory_order_acq_rel);
     hipError_t e = hipLaunchHostFunc(c->copy_stream, CopyTrack::on_start, node);
@@ -1039,8 +1106,7 @@ int run_verify_vector(DeviceCtx *c, int curve, int group, const GroupOps *ops, c
     if (!n) return PTAU_OK;
     int rc;
     const int sel = c->out_sel;
-    void *&d_out = sel ? c->d_out_alt : c->d_out;
-    size_t &d_out_cap = sel ? c->out_alt_cap : c->out_cap;
+    void *d_out = nullptr;
     c->out_sel ^= 1;
     // the compressed input: copied while the previous vector's kernels ran (Prefetch, as in contribute), or copied now
     const bool prefetched = c->prefetch.host == in && c->prefetch.bytes == n * ops->comp;
@@ -1059,13 +1125,8 @@ int run_verify_vector(DeviceCtx *c, int curve, int group, const GroupOps *ops, c
     }
     c->prefetch = DeviceCtx::Prefetch{};
     c->in_sel ^= 1;
-    if (d_out_cap < n * ops->uncomp && c->buf_copying[sel]) {   // about to be reallocated: its last reader must be done
-        HIP_TRY(hipEventSynchronize(c->bufev[sel]));
-        c->buf_copying[sel] = false;
-    }
-    if ((rc = grow(d_out, d_out_cap, n * ops->uncomp, err))) return rc;
     // the copy that last read this output buffer (two vectors ago, or another lane's) finishes before it is overwritten
-    if (c->buf_copying[sel]) HIP_TRY(hipStreamWaitEvent(c->stream, c->bufev[sel], 0));
+    if ((rc = claim_out_buffer(c, sel, n * ops->uncomp, d_out, err))) return rc;
     HIP_TRY(hipEventRecord(c->ev[3], c->stream));
     if (!prefetched) HIP_TRY(hipMemcpyAsync(d_in, in, n * ops->comp, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
@@ -1417,8 +1478,7 @@ double ptau_device_busy_ms(int device) {
 
 int ptau_last_timing(int device, ptau_timing *out) {
     if (device < 0 || device >= MAX_DEVICES || !out) return PTAU_E_ARG;
-    std::lock_guard<std::mutex> lk(g_ctx[device].mu);
-    *out = g_ctx[device].timing;
+    *out = tl_timing[device];   // the calling thread's most recent call on this device (CallTiming)
     return PTAU_OK;
 }
 
@@ -1435,9 +1495,8 @@ int ptau_apply_powers_dev(int curve, int group, const void *d_in, int compressed
     int rc = ensure_ctx(device, c, err);
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
-    HIP_TRY(hipSetDevice(device));
-    c->timing = ptau_timing{};
-    c->pending.bytes = 0;   // a copy left pending by a call that failed must never land
+    CallTiming call_timing{c, device};
+    if ((rc = begin_device_section(c, device, err))) return rc;
     return run_apply_powers_dev(c, curve, group, ops, (const uint8_t *)d_in, compressed_in, (uint8_t *)d_out, compressed_out, n, start, tau,
                                 coeff, check_input, use_endo, err);
 }
@@ -1455,9 +1514,8 @@ int ptau_apply_powers(int curve, int group, const uint8_t *in, int compressed_in
     int rc = ensure_ctx(device, c, err);
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
-    HIP_TRY(hipSetDevice(device));
-    c->timing = ptau_timing{};
-    c->pending.bytes = 0;   // a copy left pending by a call that failed must never land
+    CallTiming call_timing{c, device};
+    if ((rc = begin_device_section(c, device, err))) return rc;
     return run_apply_powers_host(c, curve, group, ops, in, compressed_in, out, compressed_out, n, start, tau, coeff, check_input, use_endo, err);
 }
 
@@ -1482,9 +1540,8 @@ int ptau_phase1_computation(const ptau_params *p, const uint8_t *in, size_t in_l
     DeviceCtx *c;
     if ((rc = ensure_ctx(device, c, err))) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
-    HIP_TRY(hipSetDevice(device));
-    c->timing = ptau_timing{};
-    c->pending.bytes = 0;   // a copy left pending by a call that failed must never land
+    CallTiming call_timing{c, device};
+    if ((rc = begin_device_section(c, device, err))) return rc;
     const uint64_t n1 = sz.g1_chunk_size, n2 = sz.other_chunk_size, s = sz.start;
     const uint8_t *pi = in + 64;
     uint8_t *po = out + 64;
@@ -1632,20 +1689,20 @@ int ptau_decompress(int curve, int group, const uint8_t *in, uint8_t *out, uint6
     int rc = ensure_ctx(device, c, err);
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
-    HIP_TRY(hipSetDevice(device));
-    c->timing = ptau_timing{};
-    c->pending.bytes = 0;   // a copy left pending by a call that failed must never land
+    CallTiming call_timing{c, device};
+    if ((rc = begin_device_section(c, device, err))) return rc;
     if (!n) return PTAU_OK;
     if ((rc = grow(c->d_in, c->in_cap, n * ops->comp, err))) return rc;
-    if ((rc = grow(c->d_out, c->out_cap, n * ops->uncomp, err))) return rc;
+    void *d_out_buf = nullptr;
+    if ((rc = claim_out_buffer(c, 0, n * ops->uncomp, d_out_buf, err))) return rc;
     HIP_TRY(hipMemcpyAsync(c->d_in, in, n * ops->comp, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-    ops->decompress(c->stream, (const uint8_t *)c->d_in, (uint8_t *)c->d_out, n, (check_output & 1), c->d_err);
+    ops->decompress(c->stream, (const uint8_t *)c->d_in, (uint8_t *)d_out_buf, n, (check_output & 1), c->d_err);
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     int bits = 0;
     HIP_TRY(hipMemcpyAsync(&bits, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(out, c->d_out, n * ops->uncomp, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(out, d_out_buf, n * ops->uncomp, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipGetLastError());
     float ms = 0;
@@ -1665,9 +1722,8 @@ int ptau_subgroup_check(int curve, int group, const uint8_t *in, int compressed_
     int rc = ensure_ctx(device, c, err);
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
-    HIP_TRY(hipSetDevice(device));
-    c->timing = ptau_timing{};
-    c->pending.bytes = 0;   // a copy left pending by a call that failed must never land
+    CallTiming call_timing{c, device};
+    if ((rc = begin_device_section(c, device, err))) return rc;
     if (!n) return PTAU_OK;
     const size_t isz = compressed_in ? ops->comp : ops->uncomp;
     if ((rc = grow(c->d_in, c->in_cap, n * isz, err))) return rc;
@@ -1906,17 +1962,9 @@ int verify_chunk_impl(const ptau_params *p, const uint8_t *challenge, size_t cha
     // no latency: BLAKE2b(new challenge) cannot start before BLAKE2b(response) has produced its header (~180 ms).
     if (before_device) (*before_device)();
     std::unique_lock<std::mutex> lk(c->mu);   // held for the device section only: pairings and digests below run unlocked
+    CallTiming call_timing{c, device};
     tr.mark("device lock taken");
-    HIP_TRY(hipSetDevice(device));
-    c->timing = ptau_timing{};
-    c->pending.bytes = 0;   // a copy left pending by a call that failed must never land
-    c->prefetch = DeviceCtx::Prefetch{};
-    for (auto &sl : c->slots)   // MSM tails left behind by a call that failed: of no interest, but their kernels must be done
-        if (sl.tail.active) {
-            HIP_TRY(hipEventSynchronize(sl.tev[2]));
-            sl.tail.active = false;
-        }
-    c->slot_next = 0;
+    if ((rc = begin_device_section(c, device, err))) return rc;
     const uint64_t n1 = sz.g1_chunk_size, n2 = sz.other_chunk_size;
     const uint8_t *pi = response + 64;
     uint8_t *po = new_challenge + 64;
@@ -1979,6 +2027,7 @@ int verify_chunk_impl(const ptau_params *p, const uint8_t *challenge, size_t cha
     vec_out[4] = po;
     if ((rc = finish_single_side(c, err))) return rc;
     po += g2->uncomp;
+    call_timing.detach();   // c->timing is the next lane's from here on; this call's record goes on in its private copy
     lk.unlock();   // another lane may use the device while this one finishes its host tail
     tr.mark("device section done");
     track.drain();   // the vectors' copies (queued, never waited for inside the device section) have landed
@@ -2030,12 +2079,10 @@ int verify_chunk_impl(const ptau_params *p, const uint8_t *challenge, size_t cha
     }
     if ((rc = fut_ratio.get())) return err.fail(rc, "%s", ratio_msg);
     tr.mark("pairing checks done");
-    {   // how many pairing checks this call ran: ratio_checks == 0 under ratio_check means "not performed" (ptau.h)
-        std::lock_guard<std::mutex> tl(c->mu);
-        c->timing.ratio_checks = (uint32_t)ratio_jobs.size();
-        c->timing.pok_checks = (uint32_t)pok_jobs.size();
-        c->timing.d2h_ms += (double)track.d2h_ns.load() / 1e6;
-    }
+    // how many pairing checks THIS call ran: ratio_checks == 0 under ratio_check means "not performed" (ptau.h)
+    call_timing.mine.ratio_checks = (uint32_t)ratio_jobs.size();
+    call_timing.mine.pok_checks = (uint32_t)pok_jobs.size();
+    call_timing.mine.d2h_ms += (double)track.d2h_ns.load() / 1e6;
     // new_challenge = BLAKE2b(response) | decompressed elements
     fut_resp.wait();
     if (!chain_ok)
@@ -2129,9 +2176,8 @@ int ptau_msm(int curve, int group, const uint8_t *in, int compressed_in, uint64_
     int rc = ensure_ctx(device, c, err);
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
-    HIP_TRY(hipSetDevice(device));
-    c->timing = ptau_timing{};
-    c->pending.bytes = 0;   // a copy left pending by a call that failed must never land
+    CallTiming call_timing{c, device};
+    if ((rc = begin_device_section(c, device, err))) return rc;
     const size_t isz = compressed_in ? ops->comp : ops->uncomp;
     const int nl64 = (ops->fr_limbs32 + 1) / 2;
     // scalars travel as 32-bit limbs; Fr of BLS12-377 has 8 of them, the 753-bit fields 24
@@ -2170,9 +2216,8 @@ int ptau_power_pairs(int curve, int group, const uint8_t *in, int compressed_in,
     int rc = ensure_ctx(device, c, err);
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
-    HIP_TRY(hipSetDevice(device));
-    c->timing = ptau_timing{};
-    c->pending.bytes = 0;   // a copy left pending by a call that failed must never land
+    CallTiming call_timing{c, device};
+    if ((rc = begin_device_section(c, device, err))) return rc;
     const size_t isz = compressed_in ? ops->comp : ops->uncomp;
     if ((rc = grow(c->d_in, c->in_cap, n * isz, err))) return rc;
     HIP_TRY(hipMemcpyAsync(c->d_in, in, n * isz, hipMemcpyHostToDevice, c->stream));
@@ -2327,10 +2372,9 @@ int combine_impl(const ptau_params *full, uint64_t chunk_size, const uint8_t *co
     DeviceCtx *c;
     if ((rc = ensure_ctx(device, c, err))) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
+    CallTiming call_timing{c, device};
     CopyTrack track;   // (after the lock: drained before the device is released and before the caller's buffers go away)
-    HIP_TRY(hipSetDevice(device));
-    c->timing = ptau_timing{};
-    c->pending.bytes = 0;   // a copy left pending by a call that failed must never land
+    if ((rc = begin_device_section(c, device, err))) return rc;
     memset(combined, 0, 64);
     // destination vector bases in the full accumulator
     uint8_t *d_tau_g1 = combined + 64;
@@ -2382,9 +2426,7 @@ int transform_ratios_impl(const ptau_params *full, const uint8_t *combined, size
     int rc = check_params(full, err);
     if (rc) return rc;
     if (!combined || !devices || n_devices < 1 || n_devices > MAX_DEVICES) return err.fail(PTAU_E_ARG, "null pointer / bad device list");
-    for (int a = 0; a < n_devices; a++)
-        for (int b = a + 1; b < n_devices; b++)
-            if (devices[a] == devices[b]) return err.fail(PTAU_E_ARG, "device %d listed twice", devices[a]);
+    // an ordinal may be listed more than once: its slices then queue on that device's lock (one GPU, several slices)
     ptau_params fp = *full;
     fp.contribution_mode = PTAU_MODE_FULL;   // a chunk-0 parameter block of the same ceremony is accepted
     ptau_sizes fs;

@@ -162,6 +162,15 @@ int main(int argc, char **argv) {
     int devs[16], nd = ptau_device_count();
     if (nd > 16) nd = 16;
     for (int i = 0; i < nd; i++) devs[i] = i;
+    const char *td = getenv("PTAU_TEST_DEVICES"); /* "0,0": two slices on one GPU (an ordinal may repeat) */
+    if (td && *td) {
+        nd = 0;
+        for (const char *q = td; *q && nd < 16;) {
+            devs[nd++] = (int)strtol(q, (char **)&q, 10);
+            if (*q == ',') q++;
+        }
+    }
+    printf("ratio_slices=%d\n", nd);
     if ((rc = ptau_transform_ratios_file_devices(&full, bnc, PTAU_CHECK_NO, devs, nd, err, sizeof err)))
         return fail("ptau_transform_ratios_file_devices", rc, err);
     printf("tail=ok\n");

@@ -120,6 +120,76 @@ def test_beacon_chain_file_level(name, pkg, tmp_path):
     assert e.value.code == -6
 
 
+@pytest.mark.parametrize("name", ["bls12_377", "bw6"])
+def test_transform_ratios_in_process_slices(name, pkg, tmp_path):
+    """ptau_transform_ratios_devices with MORE THAN ONE slice (control.rs:587-591 on a node with several GPUs; here one GPU
+    listed three times, its slices queue on the device lock): power-4 accumulator, tauG1 = 31 points = 30 pairs in slices
+    [0,10) [10,20) [20,30) (points 0..10, 10..20, 20..30: neighbours overlap by one element), the other vectors 15 pairs in
+    slices of 5.  The honest accumulator is accepted; a swap ON a slice boundary, a swap inside the last slice and a foreign
+    point in the last slice are rejected by the summed partial pairs; check_input = Full rejects an off-subgroup element of
+    slice 2 with the membership code; buffer and FILE forms."""
+    c = CURVES[name]
+    power = 4
+    d = str(tmp_path)
+    f = lambda s: os.path.join(d, s)
+    full = pkg.Phase1Parameters.new_full(name, 0, power, 1 << power)
+    _write_initial(pkg, name, full, f("c0"))
+    pkg.phase1_cli.contribute_seeded(f("c0"), f("c0.h"), f("r0"), f("r0.hash"), pkg.CheckForCorrectness.No, pkg.BatchExpMode.Auto,
+                                     full, bytes([3]) * 64)
+    pkg.transform_pok_and_correctness(f("c0"), f("v.c0.hash"), pkg.CheckForCorrectness.No, f("r0"), f("v.r0.hash"),
+                                      pkg.CheckForCorrectness.OnlyNonZero, f("acc"), f("acc.hash"), pkg.SubgroupCheckMode.Auto, True, full)
+    acc = open(f("acc"), "rb").read()
+    pfull = P.Params(c, P.FULL, 0, 1 << power, power, 1 << power)
+    assert acc == P.new_challenge_from_response(pfull, open(f("r0"), "rb").read())
+    G1, G2 = Group(c, 1), Group(c, 2)
+    u1, u2 = G1.uncomp_size, G2.uncomp_size
+    n1, n2 = full.powers_g1_length, full.powers_length
+    assert (n1, n2) == (31, 16)
+    off = {"tau_g1": 64, "tau_g2": 64 + n1 * u1, "alpha_g1": 64 + n1 * u1 + n2 * u2, "beta_g1": 64 + n1 * u1 + n2 * u2 + n2 * u1}
+    for devs in ([0], [0, 0], [0, 0, 0], [0] * 7):
+        pkg.phase1_cli.transform_ratios_devices(acc, pkg.CheckForCorrectness.No, full, devs)
+        pkg.phase1_cli.transform_ratios_devices(acc, pkg.CheckForCorrectness.Full, full, devs)
+    pkg.phase1_cli.transform_ratios_file(f("acc"), pkg.CheckForCorrectness.Full, full, devices=[0, 0, 0])
+
+    def swapped(vec, usz, i, j):
+        b = bytearray(acc)
+        o = off[vec]
+        b[o + i * usz:o + (i + 1) * usz], b[o + j * usz:o + (j + 1) * usz] = acc[o + j * usz:o + (j + 1) * usz], acc[o + i * usz:o + (i + 1) * usz]
+        return bytes(b)
+    cases = [
+        ("tau_g1 boundary 0|1 (element 10 is shared by slices 0 and 1)", swapped("tau_g1", u1, 10, 11)),
+        ("tau_g1 boundary 1|2", swapped("tau_g1", u1, 19, 20)),
+        ("tau_g1 inside the last slice", swapped("tau_g1", u1, 25, 27)),
+        ("tau_g1 last two elements", swapped("tau_g1", u1, 29, 30)),
+        ("tau_g2 boundary 0|1", swapped("tau_g2", u2, 5, 6)),
+        ("tau_g2 inside the last slice", swapped("tau_g2", u2, 12, 14)),
+        ("alpha_g1 boundary 1|2", swapped("alpha_g1", u1, 9, 10)),
+        ("beta_g1 inside the last slice", swapped("beta_g1", u1, 13, 15)),
+    ]
+    for tag, bad in cases:
+        for devs in ([0], [0, 0, 0]):
+            with pytest.raises(pkg.PtauError) as e:
+                pkg.phase1_cli.transform_ratios_devices(bad, pkg.CheckForCorrectness.No, full, devs)
+            assert e.value.code == -6, (tag, devs)
+    open(f("bad"), "wb").write(cases[0][1])
+    with pytest.raises(pkg.PtauError) as e:
+        pkg.phase1_cli.transform_ratios_file(f("bad"), pkg.CheckForCorrectness.No, full, devices=[0, 0, 0])
+    assert e.value.code == -6
+    # an element of slice 2 that is on the curve but outside the prime-order subgroup
+    rng = random.Random(4)
+    for vec, G, usz, idx in (("tau_g1", G1, u1, 26), ("tau_g2", G2, u2, 13)):
+        pt = serde.write_point(G, _off_subgroup(G, rng), False)
+        b = bytearray(acc)
+        b[off[vec] + idx * usz:off[vec] + (idx + 1) * usz] = pt
+        for devs in ([0], [0, 0, 0]):
+            with pytest.raises(pkg.PtauError) as e:
+                pkg.phase1_cli.transform_ratios_devices(bytes(b), pkg.CheckForCorrectness.Full, full, devs)
+            assert e.value.code == -5, (vec, devs)
+            with pytest.raises(pkg.PtauError) as e:      # unchecked input: the ratio check itself refuses it
+                pkg.phase1_cli.transform_ratios_devices(bytes(b), pkg.CheckForCorrectness.No, full, devs)
+            assert e.value.code == -6, (vec, devs)
+
+
 @pytest.mark.parametrize("name,cs", [("mnt4_753", 1 << 12), ("mnt6_753", 1 << 8)])
 def test_e2e_script_mnt_shapes_file_level(name, cs, pkg, cref, tmp_path):
     """The shapes e2e/e2ephase1.sh:24-25 really runs — MNT4-753 --powers 12 --chunk-size 12 (2 chunks), MNT6-753 --powers 12
@@ -239,10 +309,10 @@ def test_abi_caller_whole_transcript_tail(tmp_path):
     c = CURVES[name]
     seed = bytes(range(40, 104))
     r = subprocess.run([exe, str(tmp_path), str(c.curve_id), str(power), str(cs), "0", seed.hex(), "tail"], capture_output=True,
-                       text=True, timeout=600)
+                       text=True, timeout=600, env=dict(os.environ, PTAU_TEST_DEVICES="0,0"))
     assert r.returncode == 0, r.stderr
     out = dict(l.split("=", 1) for l in r.stdout.strip().splitlines())
-    assert out["tail"] == "ok" and out["second_combine_rc"] == "-9"
+    assert out["tail"] == "ok" and out["second_combine_rc"] == "-9" and out["ratio_slices"] == "2"
     rd = lambda s: open(os.path.join(str(tmp_path), s), "rb").read()
     pfull = P.Params(c, P.FULL, 0, cs, power, cs)
     n_chunks = pfull.num_chunks()
@@ -317,3 +387,109 @@ def test_concurrent_lanes_write_the_same_files(pkg, tmp_path):
         for t in th:
             t.join()
     assert not errors, errors
+
+
+def test_writers_wait_for_another_lanes_copy_and_timings_stay_with_their_call(pkg, tmp_path):
+    """A verification queues the device-to-host copies of its decompressed vectors and releases the device WITHOUT waiting for
+    them (capi.hip CopyTrack); the next holder of the device lock — whatever entry point — must order its writes to the two
+    output staging buffers behind those copies (claim_out_buffer).  PTAU_TEST_COPY_DELAY_MS holds every copy back by 120 ms, so
+    the copies certainly outlive the verification's device section; a second lane (contribute / decompress / apply_powers on
+    the same device, started at the same time, i.e. waiting for the lock) then runs while they are still queued.  The new
+    challenge must equal the undisturbed one.  Also: each lane reads ITS OWN call's record from ptau_last_timing — the
+    verification 4 ratio checks + 8 proof-of-knowledge checks, the other lane none (the 'ratio check not performed' signal of
+    ptau.h must not come from somebody else's call)."""
+    import hashlib
+    import threading
+    name, lg = "bls12_377", 14
+    n = 1 << lg
+    c = CURVES[name]
+    prm = pkg.Phase1Parameters.new_chunk(name, 0, 0, n, 0, lg, n)
+    f = lambda s: str(tmp_path / s)
+    pkg.new_challenge(f("c0"), f("c0.hash"), prm)
+    pkg.phase1_cli.contribute_seeded(f("c0"), f("c0.h"), f("r0"), f("r0.hash"), pkg.CheckForCorrectness.No, pkg.BatchExpMode.Auto, prm,
+                                     b"copy-order".ljust(64, b"."), device=0)
+    digest = lambda p: hashlib.blake2b(open(p, "rb").read()).digest()
+
+    def verify(tag):
+        pkg.transform_pok_and_correctness(f("c0"), f(tag + ".c.hash"), pkg.CheckForCorrectness.No, f("r0"), f(tag + ".r.hash"),
+                                          pkg.CheckForCorrectness.OnlyNonZero, f(tag + ".c1"), f(tag + ".c1.hash"), pkg.SubgroupCheckMode.Auto,
+                                          True, prm, device=0)
+        return pkg.phase1_cli.last_timing(0)
+    tm = verify("ref")
+    assert tm["ratio_checks"] == 4 and tm["pok_checks"] == 8
+    want = digest(f("ref.c1"))
+    resp = open(f("r0"), "rb").read()
+    G1 = Group(c, 1)
+    comp_g1 = resp[64:64 + n * G1.comp_size]
+    unc_g1 = open(f("ref.c1"), "rb").read()[64:64 + n * G1.uncomp_size]
+
+    def other_contribute(tag):
+        pkg.phase1_cli.contribute_seeded(f("ref.c1"), f(tag + ".h"), f(tag + ".r1"), f(tag + ".r1.hash"), pkg.CheckForCorrectness.No,
+                                         pkg.BatchExpMode.Auto, prm, b"second".ljust(64, b"."), device=0)
+
+    def other_decompress(tag):
+        assert pkg.phase1_cli.decompress(name, 1, comp_g1, n, device=0) == unc_g1
+
+    def other_apply_powers(tag):
+        pkg.phase1_cli.apply_powers(name, 1, unc_g1, n, 0, 12345, None, device=0)
+    os.environ["PTAU_TEST_COPY_DELAY_MS"] = "120"
+    try:
+        for rnd, other in enumerate((other_contribute, other_decompress, other_apply_powers, other_contribute)):
+            got, errors = {}, []
+
+            def lane_v():
+                try:
+                    got["v"] = verify("d%d" % rnd)
+                except Exception as e:   # noqa: BLE001
+                    errors.append(repr(e))
+
+            def lane_o():
+                try:
+                    other("o%d" % rnd)
+                    got["o"] = pkg.phase1_cli.last_timing(0)
+                except Exception as e:   # noqa: BLE001
+                    errors.append(repr(e))
+            tv, to = threading.Thread(target=lane_v), threading.Thread(target=lane_o)
+            tv.start()
+            to.start()
+            tv.join()
+            to.join()
+            assert not errors, errors
+            assert digest(f("d%d.c1" % rnd)) == want, "round %d (%s): the new challenge was overwritten under its copy" % (rnd, other.__name__)
+            assert digest(f("d%d.c1.hash" % rnd)) == digest(f("ref.c1.hash"))
+            assert got["v"]["ratio_checks"] == 4 and got["v"]["pok_checks"] == 8, got["v"]
+            assert got["o"]["ratio_checks"] == 0 and got["o"]["pok_checks"] == 0 and got["o"]["points"] > 0, got["o"]
+            assert got["v"]["d2h_ms"] > 0 and got["v"]["decompress_ms"] > 0
+    finally:
+        del os.environ["PTAU_TEST_COPY_DELAY_MS"]
+    assert digest(f("o0.r1")) == digest(f("o3.r1"))      # and the lane that came second was not disturbed either
+
+
+def test_prefetch_events_are_read_before_they_are_recorded_again(pkg, tmp_path):
+    """Regression check for the event race fixed in round 3 (capi.hip run_verify_vector / run_apply_powers_host): the brackets
+    of the NEXT vector's host-to-device prefetch (pev[0], pev[1]) are re-recorded for every vector, so the elapsed time of
+    vector k's copy must be read — behind a host wait for pev[1] — BEFORE vector k + 1's prefetch re-records them; reading
+    after is hipErrorNotReady (the call fails) or the time of another copy.  Both prefetch paths (verification: compressed
+    response vectors; contribution: uncompressed challenge vectors), five passes each: every call succeeds and its h2d_ms is
+    finite, non-negative and below the call's wall time."""
+    import math
+    import time
+    name, lg = "bls12_377", 13
+    n = 1 << lg
+    prm = pkg.Phase1Parameters.new_chunk(name, 0, 0, n, 0, lg, n)
+    f = lambda s: str(tmp_path / s)
+    pkg.new_challenge(f("c0"), f("c0.hash"), prm)
+    for k in range(5):
+        t0 = time.perf_counter()
+        pkg.phase1_cli.contribute_seeded(f("c0"), f("c0.h%d" % k), f("r%d" % k), f("r%d.hash" % k), pkg.CheckForCorrectness.No,
+                                         pkg.BatchExpMode.Auto, prm, bytes([k + 1]) * 64, device=0)
+        wall = (time.perf_counter() - t0) * 1e3
+        tm = pkg.phase1_cli.last_timing(0)
+        assert math.isfinite(tm["h2d_ms"]) and 0 <= tm["h2d_ms"] < wall and tm["kernel_ms"] > 0, tm
+        t0 = time.perf_counter()
+        pkg.transform_pok_and_correctness(f("c0"), f("v%d.c.hash" % k), pkg.CheckForCorrectness.No, f("r%d" % k), f("v%d.r.hash" % k),
+                                          pkg.CheckForCorrectness.OnlyNonZero, f("v%d.c1" % k), f("v%d.c1.hash" % k), pkg.SubgroupCheckMode.Auto,
+                                          True, prm, device=0)
+        wall = (time.perf_counter() - t0) * 1e3
+        tm = pkg.phase1_cli.last_timing(0)
+        assert math.isfinite(tm["h2d_ms"]) and 0 <= tm["h2d_ms"] < wall and tm["kernel_ms"] > 0 and tm["decompress_ms"] > 0, tm

@@ -300,6 +300,15 @@ def test_rust_shim_declarations_match_the_header():
     from conftest import load_package
     pkg = load_package()
     assert set(c_funcs) == set(pkg._lib.DECLARED_SYMBOLS)
+    # the documented operator call sites do not assert subgroup membership for data the caller did not check
+    # (contribute.rs:811-823 runs DEFAULT_CONTRIBUTE_CHECK_INPUT_CORRECTNESS = No on a downloaded challenge)
+    for doc in ("rust-shim/operator.patch.md", "INTEGRATION.md"):
+        text = open(os.path.join(ROOT, doc)).read()
+        calls = re.findall(r"phase1_cli::contribute\((.*?)\)[`;]", text, flags=re.S)
+        assert calls, doc
+        for call in calls:
+            assert not re.search(r"\btrue\b", call), "%s passes input_in_subgroup = true at a documented call site" % doc
+            assert re.search(r"input_in_subgroup\s*\*/\s*false", call), doc
 
 
 def test_window_paths_on_small_order_and_cofactor_points_on_host(cref):
@@ -453,7 +462,10 @@ def test_file_level_tail_argument_checks_without_gpu(pkg, tmp_path):
     buf = bytes(full.accumulator_size)
     with pytest.raises(pkg.PtauError) as e:
         pkg.phase1_cli.transform_ratios_devices(buf, 0, full, [0, 0])
-    assert e.value.code == -1 and "twice" in str(e.value)
+    assert e.value.code == -8          # a repeated ordinal is a legal slice list (ptau.h): the call gets as far as the missing device
+    with pytest.raises(pkg.PtauError) as e:
+        pkg.phase1_cli.transform_ratios_devices(buf, 0, full, [0] * 17)
+    assert e.value.code == -1
     with pytest.raises(pkg.PtauError) as e:
         pkg.phase1_cli.transform_ratios_devices(buf[:-1], 0, full, [0])
     assert e.value.code == -2
