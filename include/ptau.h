@@ -254,8 +254,10 @@ int ptau_check_same_ratio_batch(int curve, const uint8_t *checks, uint64_t n, in
 /* Phase1::initialization via phase1_cli::new_challenge (src/bin/new_setup.rs:105-109, verify_transcript.rs:322-326):
  * blank BLAKE2b hash, then every element = the group generator, uncompressed (host only, no GPU needed).
  * BLS12-377 and BW6-761 use the built-in ark-bls12-377 / ark-bw6-761 generators.  MNT4-753 / MNT6-753 return
- * PTAU_E_UNSUPPORTED: their arkworks G2 generator constants are not recoverable offline and an accumulator
- * built on any other point would not be the reference's initial challenge — use the _with_generators form. */
+ * PTAU_E_UNSUPPORTED in a build without pinned constants: their arkworks G2 generator constants are not recoverable offline
+ *  and an accumulator built on any other point would not be the reference's initial challenge — use the
+ * _with_generators form, or run tools/pin_reference.sh (it stores arkworks' own G2Affine::generator() bytes as
+ * csrc/pinned_generators.json) and rebuild: the built-in form then serves all four curves. */
 int ptau_new_challenge(const ptau_params *p, uint8_t *out, size_t out_len, char *err, size_t err_len);
 int ptau_new_challenge_file(const ptau_params *p, const char *challenge_path, const char *challenge_hash_path,
                             char *err, size_t err_len);

@@ -2276,8 +2276,10 @@ static const unsigned char *generator_bytes(int curve, int group) {
     switch (curve * 2 + (group - 1)) {
     case 0: return G::BLS_G1;   case 1: return G::BLS_G2;
     case 2: return G::BW6_G1;   case 3: return G::BW6_G2;
-    case 4: return G::MNT4_G1;  // MNT G2: not built in (see ptau_new_challenge)
+    case 4: return G::MNT4_G1;  // MNT G2: built in only once the deferred pin has supplied them (see ptau_new_challenge)
+    case 5: return G::HAVE_MNT_G2 ? G::MNT4_G2 : nullptr;
     case 6: return G::MNT6_G1;
+    case 7: return G::HAVE_MNT_G2 ? G::MNT6_G2 : nullptr;
     }
     return nullptr;
 }
@@ -2313,9 +2315,9 @@ int ptau_generator(int curve, int group, uint8_t *out, size_t out_len, char *err
     const GroupOps *ops = get_ops(curve, group);
     if (!ops) return err.fail(PTAU_E_ARG, "unknown curve/group %d/%d", curve, group);
     if (!out || out_len != (size_t)ops->uncomp) return err.fail(PTAU_E_LEN, "generator buffer must be %d bytes", ops->uncomp);
-    if (group == PTAU_G2 && (curve == PTAU_CURVE_MNT4_753 || curve == PTAU_CURVE_MNT6_753))
-        return err.fail(PTAU_E_UNSUPPORTED, "the arkworks G2 generator of this curve is not built in: pass G2Affine::generator() "
-                                            "through ptau_new_challenge_with_generators");
+    if (!generator_bytes(curve, group))
+        return err.fail(PTAU_E_UNSUPPORTED, "the arkworks G2 generator of this curve is not built in (run tools/pin_reference.sh and "
+                                            "rebuild, or pass G2Affine::generator() through ptau_new_challenge_with_generators)");
     memcpy(out, generator_bytes(curve, group), ops->uncomp);
     return PTAU_OK;
 }
@@ -2326,10 +2328,12 @@ int ptau_new_challenge(const ptau_params *p, uint8_t *out, size_t out_len, char 
     if (rc) return rc;
     // MNT4-753 / MNT6-753: ark-mnt4-753 / ark-mnt6-753's G2 generator constants are not recoverable offline (DESIGN.md
     // §2) — an accumulator built from any other generator would NOT be the reference's initial challenge, so the built-in
-    // form refuses; the Rust host passes its own G2Affine::generator() through ptau_new_challenge_with_generators.
-    if (p->curve == PTAU_CURVE_MNT4_753 || p->curve == PTAU_CURVE_MNT6_753)
-        return err.fail(PTAU_E_UNSUPPORTED, "new_challenge on MNT4-753 / MNT6-753 needs the arkworks G2 generator: use "
-                                            "ptau_new_challenge_with_generators");
+    // form refuses unless the library was built with the pinned constants (csrc/pinned_generators.json, written by
+    // tools/pin_reference.sh from arkworks' own G2Affine::generator()); the Rust host can always pass its own through
+    // ptau_new_challenge_with_generators.
+    if (!generator_bytes(p->curve, 2))
+        return err.fail(PTAU_E_UNSUPPORTED, "new_challenge on MNT4-753 / MNT6-753 needs the arkworks G2 generator: run "
+                                            "tools/pin_reference.sh and rebuild, or use ptau_new_challenge_with_generators");
     return ptau_new_challenge_with_generators(p, generator_bytes(p->curve, 1), generator_bytes(p->curve, 2), out, out_len, errbuf, err_len);
 }
 

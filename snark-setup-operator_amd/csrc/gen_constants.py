@@ -30,9 +30,21 @@ LAZY28 = {"BlsFq", "Bw6Fq"}      # base fields that also get a carry-free 28-bit
 LAZY28_WIDE = {"Mnt4Fq", "Mnt6Fq"}
 
 
-# The MNT twists' G2 generators are NOT here: ark-mnt4-753 / ark-mnt6-753's constants are not recoverable offline, so the
-# product ships none (ptau_new_challenge refuses those curves; the host passes G2Affine::generator() through
-# ptau_new_challenge_with_generators).  The tests bring their own synthetic order-r point.
+# The MNT twists' G2 generators: ark-mnt4-753 / ark-mnt6-753's constants are not recoverable offline, so the tree holds none
+# and ptau_new_challenge refuses those curves (the host passes G2Affine::generator() through
+# ptau_new_challenge_with_generators; the tests bring their own synthetic order-r point) — UNTIL the deferred pin has run:
+# tools/pin_reference.sh writes pinned_generators.json (arkworks' own G2Affine::generator() bytes, uncompressed) next to this
+# file, the next build emits them as Generators::MNT4_G2 / MNT6_G2 with HAVE_MNT_G2 = true, and the built-in form works.
+def pinned_mnt_g2():
+    import json
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pinned_generators.json")
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    g4, g6 = bytes.fromhex(d["mnt4_753"]["g2_uncompressed"]), bytes.fromhex(d["mnt6_753"]["g2_uncompressed"])
+    if (len(g4), len(g6)) != (380, 570):
+        raise SystemExit("pinned_generators.json: MNT4-753 / MNT6-753 G2 generators must be 380 / 570 bytes uncompressed")
+    return g4, g6
 
 
 BW6_G1_XY = (0x01075b020ea190c8b277ce98a477beaee6a0cfb7551b27f0ee05c54b85f56fc779017ffac15520ac11dbfcd294c2e746a17a54ce47729b905bd71fa0c9ea097103758f9a280ca27f6750dd0356133e82055928aca6af603f4088f3af66e5b43d,
@@ -510,6 +522,10 @@ def main():
     out.append("  " + gen_bytes("BW6_G2", ser(BW6_Q, *BW6_G2)))
     out.append("  " + gen_bytes("MNT4_G1", ser(MNT_A, *MNT4_G1)))
     out.append("  " + gen_bytes("MNT6_G1", ser(MNT_B, *MNT6_G1)))
+    pinned = pinned_mnt_g2()
+    out.append("  static constexpr bool HAVE_MNT_G2 = %s;   // pinned_generators.json (tools/pin_reference.sh) present at build time" % ("true" if pinned else "false"))
+    out.append("  " + gen_bytes("MNT4_G2", pinned[0] if pinned else bytes(380)))
+    out.append("  " + gen_bytes("MNT6_G2", pinned[1] if pinned else bytes(570)))
     out.append("};")
     out.append("}  // namespace ptau")
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "curve_constants.inc")
