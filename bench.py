@@ -187,6 +187,23 @@ def initial_challenge_file(pkg, curve, prm, path, hash_path):
     open(hash_path, "wb").write(pkg.calculate_hash(buf))
 
 
+def pick_workdir(need_bytes, prefix):
+    """A scratch directory for the file-level measurements with room for `need_bytes`: /dev/shm (tmpfs: the files are
+    mmap'd, written by DMA and hashed, so a disk would measure the disk), else the default temp dir; a CLEAN error when neither
+    has the room — a tmpfs that fills up ends in SIGBUS inside an mmap'd write, not in an error message."""
+    import shutil
+    import tempfile
+    cands = [c for c in ("/dev/shm", tempfile.gettempdir()) if os.path.isdir(c) and os.access(c, os.W_OK)]
+    seen = []
+    for c in cands:
+        free = shutil.disk_usage(c).free
+        seen.append("%s: %.1f GB free" % (c, free / 1e9))
+        if free >= int(need_bytes * 1.15) + (64 << 20):
+            return tempfile.mkdtemp(prefix=prefix, dir=c), c
+    raise SystemExit("bench.py: the file-level measurement needs %.1f GB of scratch space (%s) — free some, or lower --lanes / --gpus"
+                     % (need_bytes * 1.15 / 1e9, "; ".join(seen) or "no writable temp dir"))
+
+
 def whole_chunk_extras(pkg, curve, power, log2n, dev):
     """Second half of the BASELINE metric ("chunks verified/sec") and the whole-chunk contribution, on chunk 0 of a
     power-`power` ceremony of `curve` with chunk_size 2^log2n (all five vectors), through the FILE-level
@@ -199,11 +216,11 @@ def whole_chunk_extras(pkg, curve, power, log2n, dev):
     prm = pkg.Phase1Parameters.new_chunk(curve, 0, 0, n, 0, power, n)
     n1, n2 = prm.g1_chunk_size, prm.other_chunk_size
     seed0, seed1 = b"bench seed 0".ljust(64, b"."), b"bench seed 1".ljust(64, b".")
-    # the coordinator hands a contributor a challenge that came out of a verifier's subgroup checks: the operator-side
-    # integration asserts that and gets the endomorphism path; plain Auto is exact on any curve point
+    # plain Auto is what the operator integration passes (a downloaded challenge is data of unknown origin);
+    # the asserted form (a caller that ran CheckForCorrectness::Full itself) is measured beside it
     verified = int(pkg.BatchExpMode.Auto) | pkg.phase1_cli.INPUT_IN_SUBGROUP
-    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
-    d = tempfile.mkdtemp(prefix="ptau_bench_", dir=base)
+    # inputs + outputs of the single calls, up to 8 lanes' outputs at a time, the combined accumulator of the tail
+    d, base = pick_workdir(3 * prm.accumulator_size + 3 * prm.contribution_size + 8 * prm.accumulator_size, "ptau_bench_")
     f = lambda name: os.path.join(d, name)
     elems = n1 + 3 * n2 + 1
     out = {"host_blake2b": (lambda v: {0: "portable", 1: "avx2", 2: "bmi2", 3: "avx512"}.get(v, str(v)))(pkg.load_library().ptau_blake2b_implementation(-1)),
@@ -264,7 +281,7 @@ def whole_chunk_extras(pkg, curve, power, log2n, dev):
                                                   pkg.SubgroupCheckMode.Auto, True, prm, device=dev)
             def lane_contribute(k):
                 pkg.phase1_cli.contribute_seeded(f("c1"), f("L%d.h" % k), f("L%d.r1" % k), f("L%d.r1.hash" % k), pkg.CheckForCorrectness.No,
-                                                 verified, prm, seed1, device=dev)
+                                                 pkg.BatchExpMode.Auto, prm, seed1, device=dev)
             for name, fn, outs in (("verify", lane_verify, ("L%d.c1",)), ("contribute", lane_contribute, ("L%d.r1",))):
                 th = [threading.Thread(target=fn, args=(k,)) for k in range(lanes)]
                 busy0 = Lb.ptau_device_busy_ms(dev)
@@ -336,20 +353,22 @@ def macs_per_update(curve, group, endo):
     Signed 4-bit windows, 15/16 of the digits non-zero."""
     bits = SCALAR_BITS[curve]
     windows = (bits + 3 + 3) // 4
+    # FpZ (14 limbs of 28 bits, p = 1 mod 2^28: the m_i p_0 terms are additions), counted in the ISA (DESIGN.md §4.1):
+    # product 196 + 182 = 378, square 105 + 182 = 287, fused two-term product (ps_mul2, one reduction) 392 + 182 = 574
+    zm, zs, zm2 = 378, 287, 574
     if curve == "bls12_377" and group == 1:
-        m, sq = 2 * 14 * 14, 14 * 14 + 14 * 15 // 2                 # 392 / 301 (the m_i p_0 terms counted: the model of rounds 1-2)
+        m, sq = zm, zs
         dbl, madd = 2 * m + 5 * sq, 8 * m + 3 * sq
         table = 7 * madd + 50 * m + 8 * sq
         if endo:
             return (4 * 32 - 4) * dbl + 2 * 32 * 15 // 16 * madd + 32 * 15 // 16 * m + m + table
         return (4 * windows - 4) * dbl + windows * 15 // 16 * madd + table
     if curve == "bls12_377":      # G2: Fq2 over a lane pair, FpZ coefficients
-        b = 2 * 14 * 14
-        m, sq = 2 * (b + 14 * 14), 2 * b                               # per lane ONE fused two-term product (3 N^2), complex square = one product
+        m, sq = 2 * zm2, 2 * zm                                        # per lane ONE fused two-term product; complex square = one product
         dbl, madd = 2 * m + 5 * sq, 7 * m + 4 * sq
-        table = 7 * madd + 50 * m + 8 * sq + 10 * 2 * b
+        table = 7 * madd + 50 * m + 8 * sq + 10 * 2 * zm
         if endo:      # GLS: 17 windows of four 64-bit sub-scalars, psi^j on 3 of 4 entries (two Fq2-by-Fq products)
-            return (4 * 17 - 4) * dbl + 4 * 17 * 15 // 16 * madd + 3 * 17 * 15 // 16 * 2 * 2 * b + table
+            return (4 * 17 - 4) * dbl + 4 * 17 * 15 // 16 * madd + 3 * 17 * 15 // 16 * 2 * 2 * zm + table
         return (4 * windows - 4) * dbl + windows * 15 // 16 * madd + table
     m, sq = 2 * 28 * 28, 2 * 28 * 28 - 2 * 91
     if curve == "bw6":
@@ -358,8 +377,9 @@ def macs_per_update(curve, group, endo):
         if endo:
             return (4 * 48 - 4) * dbl + 2 * 48 * 15 // 16 * madd + 48 * 15 // 16 * m + m + table
         return (4 * windows - 4) * dbl + windows * 15 // 16 * madd + table
-    # MNT4 / MNT6 (k1_lazy_a.hpp): a != 0, Jacobian table entries, no endomorphism
+    # MNT4 / MNT6 (k1_lazy_a.hpp): a != 0, Jacobian table entries
     fused = lambda k: 784 * (k + 1)
+    deg = 1 if group == 1 else (2 if curve == "mnt4_753" else 3)
     if group == 1:
         M, S = m, sq
     elif curve == "mnt4_753":
@@ -367,7 +387,12 @@ def macs_per_update(curve, group, endo):
     else:
         M, S = 3 * fused(3), 3 * fused(2)
     dbl, add = M + 8 * S, 11 * M + 5 * S
-    io = 5 * m * (1 if group == 1 else (2 if curve == "mnt4_753" else 3))   # 2 converting products in, 3 out, per coefficient
+    io = 5 * m * deg   # 2 converting products in, 3 out, per coefficient
+    if endo and group == 2:
+        # GLS on the twists (psi = [t - 1]): two 377-bit halves = 96 interleaved windows over ONE table; psi of
+        # a Jacobian entry on the second half's additions = one base product per lane pair and coordinate (3 coordinates x deg pairs)
+        w2 = 96
+        return (4 * w2 - 4) * dbl + (2 * w2 * 15 // 16 + 7) * add + w2 * 15 // 16 * 3 * deg * m + io
     return (4 * windows - 4) * dbl + (windows * 15 // 16 + 7) * add + io
 
 
@@ -491,6 +516,9 @@ def main():
     ap.add_argument("--log2-points", type=int, default=None, help="override the vector length of the config")
     ap.add_argument("--cpu-sample", type=int, default=None, help="points the CPU oracle updates (parity check + cpu_baseline)")
     ap.add_argument("--no-extras", action="store_true", help="skip the whole-chunk contribute / verify measurements")
+    ap.add_argument("--lanes", type=int, default=0,
+                    help="with --config 2 / 5: WHOLE chunks through the file-level entry points with this many in-process lanes per GPU "
+                         "(the operator's --max-in-process-lane); the line's value is chunks contributed / verified per second over all ranks")
     ap.add_argument("--exact-only", "--value-path-only", dest="exact_only", action="store_true",
                     help="launch the path of `value` only (BatchExpMode::Auto; no Direct / asserted-membership lines): under rocprofv3 "
                          "every launch of the kernel is then the one `value` and `roofline` describe, so the profile's per-kernel "
@@ -541,8 +569,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.lanes and args.config not in (2, 5):
+        raise SystemExit("bench.py: --lanes measures whole BLS12-377 chunks: use it with --config 2 (contribute) or --config 5 (verify)")
     if args.config == 5:
         return bench_verify(args, pkg, dev, rank, world, dist, backend, barrier)
+    if args.lanes:
+        return bench_lanes(args, pkg, dev, rank, world, dist, backend, barrier, verify=False)
 
     cfg = CONFIGS[args.config]
 
@@ -710,10 +742,12 @@ def main():
                 run2(dc, 0, dr, 1, tau, ENDO)
                 entry["endomorphism_updates_per_s"] = n2 / (pkg.phase1_cli.last_timing(dev)["kernel_ms"] / 1e3)
                 entry["endomorphism_kernel_ms"] = pkg.phase1_cli.last_timing(dev)["scalar_mul_ms"]
+                entry["endomorphism_alu_frac"] = macs_per_update(c2, g2, endo=True) * n2 / (entry["endomorphism_kernel_ms"] / 1e3) / MAC_PEAK
             if not args.exact_only:
                 run2(dc, 0, dr, 1, tau, DIRECT)
                 entry["direct_updates_per_s"] = n2 / (pkg.phase1_cli.last_timing(dev)["kernel_ms"] / 1e3)
                 entry["direct_kernel_ms"] = pkg.phase1_cli.last_timing(dev)["scalar_mul_ms"]
+                entry["direct_alu_frac"] = macs_per_update(c2, g2, endo=False) * n2 / (entry["direct_kernel_ms"] / 1e3) / MAC_PEAK
             others["%s_G%d" % (c2, g2)] = entry
             del dc, dr
         if others:
@@ -780,6 +814,123 @@ def sharded_ratios_line(args, pkg, dev, rank, world, dist, f, prm, lg, barrier):
             shutil.rmtree(shared, ignore_errors=True)
 
 
+def bench_lanes(args, pkg, dev, rank, world, dist, backend, barrier, verify):
+    """--lanes L (with --config 2: contribute, --config 5: verify): WHOLE chunks through the file-level entry points with L
+    in-process lanes per GPU — the operator's --max-in-process-lane (contribute.rs:120-121, 467-492): L threads of ONE process per
+    GPU, each a full phase1_cli::contribute / transform_pok_and_correctness on its own file set (2^20 BLS12-377 chunk 0: 503 MB
+    challenge, 252 MB response).  A step = every lane of this rank completes one chunk.  This is the line that shows what a
+    node delivers in chunks/s: the device section of a call is 90-180 ms, the rest is the host's BLAKE2b chain, so the rate is
+    bound by host threads (about 3 busy threads per lane) long before the GPUs are — `host_threads`, `host_threads_needed`
+    and `device_busy_frac_per_rank` say where a given node stands."""
+    import shutil
+    import threading
+    import torch
+    lanes = args.lanes
+    lg = args.log2_points or 20
+    n = 1 << lg
+    prm = pkg.Phase1Parameters.new_chunk("bls12_377", 0, 0, n, 0, lg, n)
+    out_sz = prm.accumulator_size if verify else prm.contribution_size
+    d, base = pick_workdir(2 * prm.accumulator_size + prm.contribution_size + lanes * out_sz, "ptau_bench_l%d_" % rank)
+    f = lambda s: os.path.join(d, s)
+    C, seed0, seed1 = pkg.CheckForCorrectness, b"bench lanes seed 0".ljust(64, b"."), b"bench lanes seed 1".ljust(64, b".")
+    try:
+        pkg.new_challenge(f("c0"), f("c0.hash"), prm)
+        pkg.phase1_cli.contribute_seeded(f("c0"), f("c0.h2"), f("r0"), f("r0.hash"), C.No, pkg.BatchExpMode.Auto, prm, seed0, device=dev)
+        if not verify:      # contributions extend a VERIFIED challenge (genuine elements, as in a ceremony)
+            pkg.transform_pok_and_correctness(f("c0"), f("v.c.hash"), C.No, f("r0"), f("v.r.hash"), C.OnlyNonZero, f("c1"), f("c1.hash"),
+                                              pkg.SubgroupCheckMode.Auto, True, prm, device=dev)
+        dev_ms = [0.0] * lanes
+        errors = []
+
+        def lane(k):
+            try:
+                if verify:
+                    if os.path.exists(f("L%d.c1" % k)):
+                        os.remove(f("L%d.c1" % k))
+                    pkg.transform_pok_and_correctness(f("c0"), f("L%d.c.hash" % k), C.No, f("r0"), f("L%d.r.hash" % k), C.OnlyNonZero,
+                                                      f("L%d.c1" % k), f("L%d.c1.hash" % k), pkg.SubgroupCheckMode.Auto, True, prm, device=dev)
+                else:
+                    if os.path.exists(f("L%d.r1" % k)):
+                        os.remove(f("L%d.r1" % k))
+                    pkg.phase1_cli.contribute_seeded(f("c1"), f("L%d.h" % k), f("L%d.r1" % k), f("L%d.r1.hash" % k), C.No,
+                                                     pkg.BatchExpMode.Auto, prm, seed1, device=dev)
+                dev_ms[k] += pkg.phase1_cli.last_timing(dev)["kernel_ms"]      # this lane's own call (per-thread record)
+            except Exception as e:   # noqa: BLE001 - reported with the lane
+                errors.append("lane %d: %r" % (k, e))
+
+        def step():
+            th = [threading.Thread(target=lane, args=(k,)) for k in range(lanes)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            if errors:
+                raise SystemExit("bench.py --lanes: " + "; ".join(errors))
+        for _ in range(args.warmup):
+            step()
+        for k in range(lanes):
+            dev_ms[k] = 0.0
+        barrier()
+        Lb = pkg.load_library()
+        busy0 = Lb.ptau_device_busy_ms(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        busy = [(Lb.ptau_device_busy_ms(dev) - busy0) / 1e3 / dt]
+        if dist is not None:
+            allb = [None] * world
+            dist.all_gather_object(allb, busy[0])
+            busy = allb
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        # every lane's output is the single-lane output (hash chain header checked here; tests/test_gpu_tail.py compares whole files)
+        for k in range(lanes):
+            if verify:
+                assert open(f("L%d.c1" % k), "rb").read(64) == open(f("L%d.r.hash" % k), "rb").read()
+            else:
+                assert open(f("L%d.r1" % k), "rb").read(64) == open(f("L%d.h" % k), "rb").read()
+        if rank == 0:
+            chunks = world * lanes * args.steps
+            elems = prm.g1_chunk_size + 3 * prm.other_chunk_size + 1
+            ncpu = os.cpu_count() or 0
+            try:
+                ncpu = len(os.sched_getaffinity(0))
+            except Exception:   # noqa: BLE001
+                pass
+            per_lane_threads = 3.0      # a lane's launching thread + two BLAKE2b / page-population workers busy at a time (INTEGRATION.md §4)
+            print(json.dumps({
+                "metric": "chunks verified/sec" if verify else "chunks contributed/sec",
+                "value": chunks / dt, "unit": "chunks %s/s" % ("verified" if verify else "contributed"),
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+                "config": {"workload": "whole 2^%d BLS12-377 chunks (chunk 0: %d elements, challenge %d B, response %d B) through the "
+                                       "file-level %s, %d in-process lanes per GPU x %d GPU(s), files on %s; BLAKE2b chain, key "
+                                       "generation / proofs of knowledge, PCIe inside the step"
+                                       % (lg, elems, prm.accumulator_size, prm.contribution_size,
+                                          "phase1_cli::transform_pok_and_correctness (ratio check on)" if verify else
+                                          "phase1_cli::contribute (BatchExpMode::Auto, CheckForCorrectness::No: the operator's default flags)",
+                                          lanes, world, base),
+                           "baseline_config": 5 if verify else 2, "lanes_per_gpu": lanes, "chunks_per_step": world * lanes},
+                "chunks_per_s": chunks / dt, "chunks_per_s_per_gpu": lanes * args.steps / dt,
+                "g1_equiv_updates_per_s": chunks * elems / dt,
+                "device_ms_per_chunk_rank0": sum(dev_ms) / (lanes * args.steps),
+                "device_busy_frac_per_rank": busy,
+                "host_threads": ncpu, "host_threads_needed": world * lanes * per_lane_threads,
+                "host_bound": world * lanes * per_lane_threads > ncpu,
+                "note": "the rate of whole chunks is bound by the host (one sequential BLAKE2b stream per file, ~1.3 GB/s per core) "
+                        "long before the GPU: device_busy_frac says how much of the wall time the GPU had kernels running; "
+                        "host_threads_needed = lanes x ranks x ~3 busy threads — on a node with fewer host threads more GPUs do not "
+                        "add chunks/s (INTEGRATION.md §4)"}))
+    finally:
+        barrier()
+        shutil.rmtree(d, ignore_errors=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def bench_verify(args, pkg, dev, rank, world, dist, backend, barrier):
     """--config 5: verification of one 2^20 BLS12-377 chunk per GPU (BASELINE configs[4], second half of the metric).  A step =
     phase1_cli::transform_pok_and_correctness on chunk 0 (files on tmpfs, ratio check on): the boundary of this path is the
@@ -790,8 +941,11 @@ def bench_verify(args, pkg, dev, rank, world, dist, backend, barrier):
     lg = args.log2_points or 20
     n = 1 << lg
     prm = pkg.Phase1Parameters.new_chunk("bls12_377", 0, 0, n, 0, lg, n)
-    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
-    d = tempfile.mkdtemp(prefix="ptau_bench_v%d_" % rank, dir=base)
+    if args.lanes:
+        return bench_lanes(args, pkg, dev, rank, world, dist, backend, barrier, verify=True)
+    # this rank's files (challenge, response, new challenge, the tauG1-only chunk of the tail) + rank 0's combined accumulator
+    full_sz = pkg.Phase1Parameters.new_full("bls12_377", 0, lg, n).accumulator_size
+    d, base = pick_workdir(3 * prm.accumulator_size + 2 * prm.contribution_size + (full_sz if rank == 0 else 0), "ptau_bench_v%d_" % rank)
     f = lambda s: os.path.join(d, s)
     try:
         pkg.new_challenge(f("c0"), f("c0.hash"), prm)

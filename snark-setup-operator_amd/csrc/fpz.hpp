@@ -392,6 +392,35 @@ struct LazyJac {
         return r;
     }
 
+    // The same addition with the entry's coordinates read WHERE THE FORMULA CONSUMES THEM (src.x(), src.y(): a table read,
+    // plus the endomorphism's beta product on the GLV path) and ordered for liveness, as LazyJac2::add_src: Z3 = 2 Z1 H is
+    // taken as soon as H exists (Z1 and Z1Z1 retire), the exceptional cases are decided by two early flags and rebuilt from
+    // the entry at the single join.  At most six elements are alive at any product call — what the lane-split field
+    // (BW6-761: 14 VGPRs per element and lane, register-ABI product calls) needs to keep the window loop out of scratch.
+    template <class Src>
+    PTAU_HD static LazyJac add_src(const LazyJac &p, const Src &src) {
+        const bool pinf = p.is_inf();
+        const auto Z1Z1 = Z::sqr(p.Zc);
+        const auto H = Z::norm(Z::sub(Z::mul(src.x(), Z1Z1), p.X));
+        const auto rh = Z::norm(Z::sub(Z::mul(Z::mul(src.y(), p.Zc), Z1Z1), p.Y));
+        const bool hz = Z::is_zero(H), rz = Z::is_zero(rh);
+        LazyJac r;
+        r.Zc = Z::mul(Z::template times<2>(p.Zc), H);
+        const auto I = Z::template times<4>(Z::sqr(H));
+        const auto J = Z::mul(H, I);
+        const auto Vv = Z::mul(p.X, I);
+        const auto rr = Z::template times<2>(rh);
+        r.X = Z::norm(Z::sub(Z::sqr(rr), Z::add(J, Z::template times<2>(Vv))));
+        r.Y = Z::norm(Z::sub(Z::mul(rr, Z::sub(Vv, r.X)), Z::template times<2>(Z::mul(p.Y, J))));
+        if (pinf || hz) {   // one join, rare paths, everything rebuilt from the entry
+            const LazyJac q = {src.x(), Z::norm(src.y()), Z::one()};
+            if (pinf) r = q;
+            else if (rz) r = dbl(q);
+            else r = infinity();
+        }
+        return r;
+    }
+
     // madd-2007-bl with Z3 = 2 Z1 H; q = (x2, y2) affine and not the point at infinity
     PTAU_HD static LazyJac add_mixed(const LazyJac &p, const AX &x2, const AY &y2) {
         const auto Z1Z1 = Z::sqr(p.Zc);
@@ -601,28 +630,48 @@ struct LazyJac2 {
         r.Y = K::reduce(K::sub(K::mul(E3, K::sub(D, r.X)), K::template times<8>(C)));
         return r;
     }
+    // The second operand of an addition held in registers (the table build adds P itself seven times).
+    struct FromRegs {
+        const AX &x_;
+        const AY &y_;
+        PTAU_HD AX x() const { return x_; }
+        PTAU_HD AY y() const { return y_; }
+    };
     // q = (x2, y2) affine, not the point at infinity
-    PTAU_HD static LazyJac2 add_mixed(const LazyJac2 &p, const AX &x2, const AY &y2) {
-        if (p.is_inf()) return {K::reduce(x2), K::reduce(y2), K::one()};
+    PTAU_HD static LazyJac2 add_mixed(const LazyJac2 &p, const AX &x2, const AY &y2) { return add_src(p, FromRegs{x2, y2}); }
+
+    // madd-2007-bl, ORDERED FOR LIVENESS.  Every product is a register-ABI call that leaves the caller the callee-saved half of
+    // v32-v255 (112 VGPRs = eight 14-limb elements); whatever is alive across a call beyond that is a scratch store and a
+    // reload (the round-3 form kept up to ten elements alive: 915 spilled VGPRs, 66 scratch dwords per point operation).  Here
+    //   * the entry's coordinates come from `src` WHERE THE FORMULA CONSUMES THEM (src.x(), src.y(): one use each; for the GLS
+    //     loop that is a table read plus psi^h, formed at that point), never held across other products;
+    //   * Z3 = (Z1 + H)^2 - Z1Z1 - HH is taken as soon as HH exists, which retires Z1 and Z1Z1 before J, V and the results;
+    //   * the exceptional cases (p = O, q = +-p) are decided from two flags taken when H and rh exist and REBUILT FROM THE ENTRY
+    //     at the single join (q = p means 2p = 2q, q being affine), so p's coordinates die as the formula consumes them.
+    // At most seven elements are alive at any call (X Y Zc Z1Z1 H rh + HH), six from there on.
+    template <class Src>
+    PTAU_HD static LazyJac2 add_src(const LazyJac2 &p, const Src &src) {
+        const bool pinf = p.is_inf();
         const auto Z1Z1 = K::sqr(p.Zc);
-        const auto U2 = K::mul(x2, Z1Z1);
-        const auto S2 = K::mul(K::mul(y2, p.Zc), Z1Z1);
-        const auto H = K::norm(K::sub(U2, p.X));     // <1, 17>
-        const auto rh = K::norm(K::sub(S2, p.Y));    // <1, 17>
-        if (K::is_zero(H)) {   // pair-uniform
-            if (K::is_zero(rh)) return dbl(p);
-            return infinity();
-        }
-        const auto R2 = K::template times<4>(K::sqr(rh));   // (2 rh)^2
+        const auto H = K::norm(K::sub(K::mul(src.x(), Z1Z1), p.X));                      // <1, 6>
+        const auto rh = K::norm(K::sub(K::mul(K::mul(src.y(), p.Zc), Z1Z1), p.Y));       // <1, 6>
+        const bool hz = K::is_zero(H), rz = K::is_zero(rh);   // pair-uniform
         const auto HH = K::sqr(H);
+        LazyJac2 r;
+        // Z3 = (Z1 + H)^2 - Z1^2 - H^2: a square is ONE base product per lane where the product 2 Z1 H is two
+        r.Zc = K::norm(K::sub(K::sqr(K::norm(K::add(p.Zc, H))), K::add(Z1Z1, HH)));
         const auto I = K::template times<4>(HH);
         const auto J = K::mul(H, I);
         const auto Vv = K::mul(p.X, I);
-        LazyJac2 r;
+        const auto R2 = K::template times<4>(K::sqr(rh));   // (2 rh)^2
         r.X = K::reduce(K::sub(R2, K::add(J, K::template times<2>(Vv))));
         r.Y = K::reduce(K::sub(K::mul(K::template times<2>(rh), K::sub(Vv, r.X)), K::template times<2>(K::mul(p.Y, J))));
-        // Z3 = (Z1 + H)^2 - Z1^2 - H^2: a square is ONE base product per lane where the product 2 Z1 H is two
-        r.Zc = K::norm(K::sub(K::sqr(K::norm(K::add(p.Zc, H))), K::add(Z1Z1, HH)));
+        if (pinf || hz) {   // one join, rare paths, everything rebuilt from the entry
+            const LazyJac2 q = {K::reduce(src.x()), K::reduce(src.y()), K::one()};
+            if (pinf) r = q;
+            else if (rz) r = dbl(q);
+            else r = infinity();
+        }
         return r;
     }
 };

@@ -360,6 +360,9 @@ def main():
                 assert abs(v) < 1 << 192
             assert g1 < 1 << 224 and g2 < 1 << 224
             s.append("  static constexpr uint32_t GLV_BETA[%d] = {%s};" % (n, limbs(beta * R % p, n)))
+            if fname.endswith("R29") and fname[:-3] in LAZY28:   # the same constant in the carry-free twin field: a literal in the loop
+                nz = (p.bit_length() + 15 + 27) // 28
+                s.append("  static constexpr uint32_t GLV_BETAZ[%d] = {%s};" % (nz, limbs(beta * (1 << (28 * nz)) % p, nz, 28)))
             s.append("  static constexpr uint32_t GLV2_A1[6] = {%s};" % limbs(abs(a1), 6, 32))
             s.append("  static constexpr uint32_t GLV2_A2[6] = {%s};" % limbs(abs(a2), 6, 32))
             s.append("  static constexpr uint32_t GLV2_B1[6] = {%s};" % limbs(abs(b1), 6, 32))
@@ -388,6 +391,9 @@ def main():
             beta, lam = glv
             assert lam.bit_length() <= 127
             s.append("  static constexpr uint32_t GLV_BETA[%d] = {%s};" % (n, limbs(beta * R % p, n)))
+            if fname.endswith("R29") and fname[:-3] in LAZY28:
+                nz = (p.bit_length() + 15 + 27) // 28
+                s.append("  static constexpr uint32_t GLV_BETAZ[%d] = {%s};" % (nz, limbs(beta * (1 << (28 * nz)) % p, nz, 28)))
             s.append("  static constexpr uint32_t GLV_LAMBDA[4] = {%s};" % limbs(lam, 4, 32))
             s.append("  static constexpr uint32_t GLV_M[5] = {%s};" % limbs((1 << 256) // lam, 5, 32))
         # #E / r (ark-*'s COFACTOR): G::rand and hash_to_g2 clear it (key generation, host side); tests/test_oracle.py

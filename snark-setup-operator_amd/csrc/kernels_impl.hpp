@@ -529,6 +529,11 @@ struct LazyOf {
 #pragma unroll
         for (int j = 0; j < N; j++) w[j] = 0;
     }
+    PTAU_HD static bool all_lanes(bool mine) {   // true in every lane that holds a part of this point
+        if constexpr (PAIR) return K::both(mine);
+        else if constexpr (SPLIT) return LZ::both(mine);
+        else return mine;
+    }
 };
 
 template <class G, bool LAZY>
@@ -575,22 +580,47 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
         using KM = typename LoopAcc<G, true>::zc_type;
         static_assert(sizeof(J) >= 2 * L::N * sizeof(uint32_t), "a converted entry must fit the Jacobian slot");
         auto slot_w = [&](int e) { return reinterpret_cast<uint32_t *>(&wtab[(uint64_t)e * nslots + slot]); };
-        const typename L::C px = L::to_lazy(p.x), py = L::to_lazy(p.y);
-        const typename L::AX pxa = px;
-        const typename L::AY pya = py;
-        AccT cur = {px, py, K::one()};
-        decltype(cur.Zc) zs[WINDOW_ENTRIES - 1];
+        // Liveness (see LazyJac2::add_src): an addition keeps up to seven field elements alive across its product calls, and
+        // the callee-saved registers hold eight.  So nothing else lives in registers over the table's additions: P itself is
+        // parked in entry 0's slot (unscaled; rescaled last) and read back where the formula consumes it, and the running
+        // product of the Z's is taken in a pass of its own.
+        uint32_t *const w0 = slot_w(0);
+        decltype(AccT{}.Zc) zs[WINDOW_ENTRIES - 1];
         KM pre[WINDOW_ENTRIES - 1];
+        {
+            const typename L::C px = L::to_lazy(p.x), py = L::to_lazy(p.y);
+            L::store(w0, px);
+            L::store(w0 + L::N, py);
+            struct ParkedP {   // (x, y) of P from entry 0's slot; volatile: the reads stay where the formula uses them
+                const uint32_t *w;
+                PTAU_HD typename L::C coord(int c) const {
+                    const volatile uint32_t *q = w + c * L::N;
+                    typename L::C v;
+#pragma unroll
+                    for (int j = 0; j < L::N; j++) {
+                        if constexpr (L::PAIR) v.c.l[j] = q[j];
+                        else v.l[j] = q[j];
+                    }
+                    return v;
+                }
+                PTAU_HD typename L::AX x() const { return coord(0); }
+                PTAU_HD typename L::AY y() const { return coord(1); }
+            };
+            AccT cur = {px, py, K::one()};
+#pragma nounroll
+            for (int e = 1; e < WINDOW_ENTRIES; e++) {
+                cur = AccT::add_src(cur, ParkedP{w0});
+                uint32_t *w = slot_w(e);
+                L::store(w, cur.X);
+                L::store(w + L::N, cur.Y);
+                zs[e - 1] = cur.Zc;
+            }
+        }
         KM zl = K::one();
 #pragma nounroll
         for (int e = 1; e < WINDOW_ENTRIES; e++) {
-            cur = AccT::add_mixed(cur, pxa, pya);
-            uint32_t *w = slot_w(e);
-            L::store(w, cur.X);
-            L::store(w + L::N, cur.Y);
-            zs[e - 1] = cur.Zc;
             pre[e - 1] = zl;
-            if (!K::is_zero(cur.Zc)) zl = K::mul(zl, cur.Zc);
+            if (!K::is_zero(zs[e - 1])) zl = K::mul(zl, zs[e - 1]);
         }
         // Fq2: a REAL common denominator Zc conj(Zc), so that psi keeps entries on it (see below)
         auto suf = [&] {
@@ -608,8 +638,8 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
                 const KM c = K::mul(pre[e - 1], suf);
                 suf = K::mul(suf, ze);
                 const auto c2 = K::sqr(c);
-                const KM x = K::mul(L::template load<decltype(cur.X)>(w), c2);
-                const KM y = K::mul(L::template load<decltype(cur.Y)>(w + L::N), K::mul(c2, c));
+                const KM x = K::mul(L::template load<decltype(AccT{}.X)>(w), c2);
+                const KM y = K::mul(L::template load<decltype(AccT{}.Y)>(w + L::N), K::mul(c2, c));
                 L::store(w, x);
                 L::store(w + L::N, y);
             }
@@ -618,9 +648,8 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
             if constexpr (L::PAIR) zcz = K::mul(zl, K::conj(zl));
             else zcz = zl;
             const auto c2 = K::sqr(zcz);
-            uint32_t *w = slot_w(0);
-            L::store(w, KM(K::mul(px, c2)));
-            L::store(w + L::N, KM(K::mul(py, K::mul(c2, zcz))));
+            L::store(w0, KM(K::mul(L::template load<typename L::C>(w0), c2)));
+            L::store(w0 + L::N, KM(K::mul(L::template load<typename L::C>(w0 + L::N), K::mul(c2, zcz))));
         }
     }
     J cur = J::infinity();
@@ -681,18 +710,52 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
     // acc += (+-) table entry `mag` (with the GLV endomorphism applied when `endo`): a mixed addition on an affine table
     auto add_entry = [&](AccT &acc, int mag, bool negate, bool endo, const auto &beta) {
         if constexpr (G::LAZY_LOOP) {
+            // the entry read WHERE THE ADDITION CONSUMES IT (add_src): x (times beta under the endomorphism: a literal of the
+            // carry-free field) and y (negated for a negative digit); volatile reads, so the loads stay between the product calls
             using K = typename L::K;
-            const uint32_t *w = reinterpret_cast<const uint32_t *>(&wtab[(uint64_t)(mag - 1) * nslots + slot]);
             using KM = typename LoopAcc<G, true>::zc_type;
-            typename L::AX x = L::template load<KM>(w);
-            const KM y = L::template load<KM>(w + L::N);
-            if (K::limbs_all_zero(x) && K::limbs_all_zero(y)) return;   // the multiple is O
-            if constexpr (!L::PAIR) {
-                if (endo) x = K::mul(x, beta);
-            }
-            typename L::AY ys = y;
-            if (negate) ys = K::neg(y);
-            acc = AccT::add_mixed(acc, x, ys);
+            struct Entry {
+                const uint32_t *w;
+                bool endo, negate;
+                PTAU_HD KM coord(int c) const {
+                    const volatile uint32_t *q = w + c * L::N;
+                    KM v;
+#pragma unroll
+                    for (int j = 0; j < L::N; j++) {
+                        if constexpr (L::PAIR) v.c.l[j] = q[j];
+                        else v.l[j] = q[j];
+                    }
+                    return v;
+                }
+                PTAU_HD typename L::AX x() const {
+                    KM v = coord(0);
+                    if constexpr (!L::PAIR && J::CfgT::GLV_KIND != 0) {
+                        if (endo) {
+                            typename L::LZ::template E<1, 1> b;
+#pragma unroll
+                            for (int j = 0; j < L::N; j++) {
+                                if constexpr (L::SPLIT) b.l[j] = L::LZ::mine(J::CfgT::GLV_BETAZ, j);
+                                else b.l[j] = J::CfgT::GLV_BETAZ[j];
+                            }
+                            v = K::mul(v, b);
+                        }
+                    }
+                    return v;
+                }
+                PTAU_HD typename L::AY y() const {
+                    const KM v = coord(1);
+                    typename L::AY r = v;
+                    if (negate) r = K::neg(v);
+                    return r;
+                }
+            };
+            const uint32_t *w = reinterpret_cast<const uint32_t *>(&wtab[(uint64_t)(mag - 1) * nslots + slot]);
+            uint32_t any = 0;   // (0, 0) marks a multiple that is O: OR of the entry's limbs, over the lanes of the point
+#pragma unroll
+            for (int j = 0; j < 2 * L::N; j++) any |= w[j];
+            if (L::all_lanes(any == 0)) return;
+            (void)beta;
+            acc = AccT::add_src(acc, Entry{w, endo, negate});
         } else if constexpr (G::AFFINE_TABLE) {
             const J *t = &wtab[(uint64_t)(mag - 1) * nslots + slot];
             A q;
@@ -758,10 +821,9 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
 #pragma unroll
                 for (int j = 0; j < HL; j++) kk[h][j] = addc(kk[h][j], 0x88888888u, c2);   // halves < 2^(32 HL - 1): no carry out
             }
-            const F beta29 = F::load_const(Cfg::GLV_BETA);
-            const auto beta = [&] {
-                if constexpr (G::LAZY_LOOP) return L::to_lazy(beta29);
-                else return beta29;
+            const auto beta = [&] {   // (the carry-free loop takes beta as a literal where it is used: Entry::x)
+                if constexpr (G::LAZY_LOOP) return 0;
+                else return F::load_const(Cfg::GLV_BETA);
             }();
             AccT acc = AccT::infinity();
             for (int w = HL * 8 - 1; w >= 0; w--) {
@@ -816,27 +878,43 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
                     if (dgt != 0) {
                         const int mag = dgt < 0 ? -dgt : dgt;
                         if constexpr (G::LAZY_LOOP) {
+                            // psi^h of the table entry, formed WHERE THE ADDITION CONSUMES IT (LazyJac2::add_src): conjugate for
+                            // odd h, then one Fq constant per coordinate; volatile reads so that the loads are not hoisted above
+                            // the product calls in between (a coordinate held across them is a spill)
                             using K = typename L::K;
-                            const uint32_t *tw = reinterpret_cast<const uint32_t *>(&wtab[(uint64_t)(mag - 1) * nslots + slot]);
                             using KM = typename LoopAcc<G, true>::zc_type;
-                            KM x = L::template load<KM>(tw), y = L::template load<KM>(tw + L::N);
-                            if (!(K::limbs_all_zero(x) && K::limbs_all_zero(y))) {
-                                if (h) {   // psi^h of the entry: conjugate for odd h, then one Fq constant per coordinate
-                                    typename L::LZ::template E<1, 1> cx, cy;
+                            struct GlsEntry {
+                                const uint32_t *tw;
+                                int h;
+                                bool negate;
+                                PTAU_HD KM coord(int c) const {
+                                    const volatile uint32_t *w = tw + c * L::N;
+                                    KM v;
 #pragma unroll
-                                    for (int j = 0; j < L::N; j++) { cx.l[j] = Cfg::GLS_CZ[2 * (h - 1)][j]; cy.l[j] = Cfg::GLS_CZ[2 * (h - 1) + 1][j]; }
-                                    decltype(K::conj(x)) xc = x, yc = y;
-                                    if (h & 1) {
-                                        xc = K::conj(x);
-                                        yc = K::conj(y);
+                                    for (int j = 0; j < L::N; j++) v.c.l[j] = w[j];
+                                    if (h) {
+                                        typename L::LZ::template E<1, 1> k;
+#pragma unroll
+                                        for (int j = 0; j < L::N; j++) k.l[j] = Cfg::GLS_CZ[2 * (h - 1) + c][j];
+                                        decltype(K::conj(v)) vc = v;
+                                        if (h & 1) vc = K::conj(v);
+                                        v = K::mul_base(vc, k);
                                     }
-                                    x = K::mul_base(xc, cx);
-                                    y = K::mul_base(yc, cy);
+                                    return v;
                                 }
-                                typename L::AY ys = y;
-                                if (dgt < 0) ys = K::neg(y);
-                                acc = AccT::add_mixed(acc, x, ys);
-                            }
+                                PTAU_HD typename L::AX x() const { return coord(0); }
+                                PTAU_HD typename L::AY y() const {
+                                    const KM v = coord(1);
+                                    typename L::AY r = v;
+                                    if (negate) r = K::neg(v);
+                                    return r;
+                                }
+                            };
+                            const uint32_t *tw = reinterpret_cast<const uint32_t *>(&wtab[(uint64_t)(mag - 1) * nslots + slot]);
+                            uint32_t any = 0;   // (0, 0) marks a multiple that is O: OR of the entry's 2 N limbs, both lanes
+#pragma unroll
+                            for (int j = 0; j < 2 * L::N; j++) any |= tw[j];
+                            if (!L::all_lanes(any == 0)) acc = AccT::add_src(acc, GlsEntry{tw, h, dgt < 0});
                         } else {
                         J ent = wtab[(uint64_t)(mag - 1) * nslots + slot];   // affine table: Z slot unused (real common Z)
                         if (h) {
