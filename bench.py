@@ -187,6 +187,31 @@ def initial_challenge_file(pkg, curve, prm, path, hash_path):
     open(hash_path, "wb").write(pkg.calculate_hash(buf))
 
 
+def host_cpu_share():
+    """Host threads this process may actually run at once: the affinity mask, capped by the cgroup's CPU quota (a container
+    on a 256-thread host with `cpu.max = 1600000 100000` has 16)."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:   # noqa: BLE001
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except Exception:   # noqa: BLE001
+            continue
+    return n
+
+
 def pick_workdir(need_bytes, prefix):
     """A scratch directory for the file-level measurements with room for `need_bytes`: /dev/shm (tmpfs: the files are
     mmap'd, written by DMA and hashed, so a disk would measure the disk), else the default temp dir; a CLEAN error when neither
@@ -895,11 +920,7 @@ def bench_lanes(args, pkg, dev, rank, world, dist, backend, barrier, verify):
         if rank == 0:
             chunks = world * lanes * args.steps
             elems = prm.g1_chunk_size + 3 * prm.other_chunk_size + 1
-            ncpu = os.cpu_count() or 0
-            try:
-                ncpu = len(os.sched_getaffinity(0))
-            except Exception:   # noqa: BLE001
-                pass
+            ncpu = host_cpu_share()
             per_lane_threads = 3.0      # a lane's launching thread + two BLAKE2b / page-population workers busy at a time
             print(json.dumps({
                 "metric": "chunks verified/sec" if verify else "chunks contributed/sec",

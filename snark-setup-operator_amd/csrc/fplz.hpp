@@ -403,6 +403,13 @@ struct FpLZ {
         for (int i = 0; i < H; i++) o |= a.l[i];
         return both(o == 0);
     }
+    template <int U, int V>
+    PTAU_HD static bool limbs_all_zero_local(const E<U, V> &a) {   // this lane's half only
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < H; i++) o |= a.l[i];
+        return o == 0;
+    }
 
     // FpL (29-bit limbs, fully reduced) <-> this representation; off the hot path: through the whole element in each lane
     PTAU_HD static Nrm from29(const L29 &a) {

@@ -312,6 +312,9 @@ struct FpZ {
         return o == 0;
     }
 
+    template <int U, int V>
+    PTAU_HD static bool limbs_all_zero_local(const E<U, V> &a) { return limbs_all_zero(a); }   // (one lane holds the element)
+
     // Fp29 (fully reduced, R29 = 2^(29 N29)) <-> this representation
     PTAU_HD static Nrm from29(const F29 &a) {
         E<1, 1> t;
@@ -392,17 +395,21 @@ struct LazyJac {
         return r;
     }
 
-    // The same addition with the entry's coordinates read WHERE THE FORMULA CONSUMES THEM (src.x(), src.y(): a table read,
-    // plus the endomorphism's beta product on the GLV path) and ordered for liveness, as LazyJac2::add_src: Z3 = 2 Z1 H is
-    // taken as soon as H exists (Z1 and Z1Z1 retire), the exceptional cases are decided by two early flags and rebuilt from
-    // the entry at the single join.  At most six elements are alive at any product call — what the lane-split field
-    // (BW6-761: 14 VGPRs per element and lane, register-ABI product calls) needs to keep the window loop out of scratch.
+    // The same addition ORDERED FOR LIVENESS, as LazyJac2::add_src: the entry's coordinates come from `src` — BOTH read at the
+    // top (one memory latency for the pair; a read per use exposed a latency each: measured 10 % slower on BLS12-377 G1) and
+    // dead after the second and fourth product; Z3 = 2 Z1 H is taken as soon as H exists (Z1 and Z1Z1 retire); the exceptional
+    // cases are decided by two early flags and REBUILT FROM THE ENTRY (src.x_again(), src.y_again(): a re-read on the rare
+    // path) at the single join, so neither p's nor the entry's coordinates stay alive for them.  At most seven elements are
+    // alive at any product call — what the lane-split field (BW6-761: 14 VGPRs per element and lane, register-ABI product
+    // calls, eight elements of callee-saved registers) needs to keep the window loop out of scratch.
     template <class Src>
     PTAU_HD static LazyJac add_src(const LazyJac &p, const Src &src) {
+        const AX x2 = src.x();
+        const AY y2 = src.y();
         const bool pinf = p.is_inf();
         const auto Z1Z1 = Z::sqr(p.Zc);
-        const auto H = Z::norm(Z::sub(Z::mul(src.x(), Z1Z1), p.X));
-        const auto rh = Z::norm(Z::sub(Z::mul(Z::mul(src.y(), p.Zc), Z1Z1), p.Y));
+        const auto H = Z::norm(Z::sub(Z::mul(x2, Z1Z1), p.X));
+        const auto rh = Z::norm(Z::sub(Z::mul(Z::mul(y2, p.Zc), Z1Z1), p.Y));
         const bool hz = Z::is_zero(H), rz = Z::is_zero(rh);
         LazyJac r;
         r.Zc = Z::mul(Z::template times<2>(p.Zc), H);
@@ -413,7 +420,7 @@ struct LazyJac {
         r.X = Z::norm(Z::sub(Z::sqr(rr), Z::add(J, Z::template times<2>(Vv))));
         r.Y = Z::norm(Z::sub(Z::mul(rr, Z::sub(Vv, r.X)), Z::template times<2>(Z::mul(p.Y, J))));
         if (pinf || hz) {   // one join, rare paths, everything rebuilt from the entry
-            const LazyJac q = {src.x(), Z::norm(src.y()), Z::one()};
+            const LazyJac q = {src.x_again(), Z::norm(src.y_again()), Z::one()};
             if (pinf) r = q;
             else if (rz) r = dbl(q);
             else r = infinity();
@@ -598,6 +605,8 @@ struct Fp2Z {
     PTAU_HD static bool is_zero(const E<1, V> &a) { return both(Z::is_zero(a.c)); }
     template <int U, int V>
     PTAU_HD static bool limbs_all_zero(const E<U, V> &a) { return both(Z::limbs_all_zero(a.c)); }
+    template <int U, int V>
+    PTAU_HD static bool limbs_all_zero_local(const E<U, V> &a) { return Z::limbs_all_zero(a.c); }   // this lane's coefficient only
 };
 
 // Jacobian arithmetic on y^2 = x^3 + b' over Fp2Z (a = 0).  Coordinates between operations: X and Y reduced below 3p, Z
@@ -630,12 +639,14 @@ struct LazyJac2 {
         r.Y = K::reduce(K::sub(K::mul(E3, K::sub(D, r.X)), K::template times<8>(C)));
         return r;
     }
-    // The second operand of an addition held in registers (the table build adds P itself seven times).
+    // The second operand of an addition held in registers.
     struct FromRegs {
         const AX &x_;
         const AY &y_;
         PTAU_HD AX x() const { return x_; }
         PTAU_HD AY y() const { return y_; }
+        PTAU_HD AX x_again() const { return x_; }
+        PTAU_HD AY y_again() const { return y_; }
     };
     // q = (x2, y2) affine, not the point at infinity
     PTAU_HD static LazyJac2 add_mixed(const LazyJac2 &p, const AX &x2, const AY &y2) { return add_src(p, FromRegs{x2, y2}); }
@@ -643,18 +654,21 @@ struct LazyJac2 {
     // madd-2007-bl, ORDERED FOR LIVENESS.  Every product is a register-ABI call that leaves the caller the callee-saved half of
     // v32-v255 (112 VGPRs = eight 14-limb elements); whatever is alive across a call beyond that is a scratch store and a
     // reload (the round-3 form kept up to ten elements alive: 915 spilled VGPRs, 66 scratch dwords per point operation).  Here
-    //   * the entry's coordinates come from `src` WHERE THE FORMULA CONSUMES THEM (src.x(), src.y(): one use each; for the GLS
-    //     loop that is a table read plus psi^h, formed at that point), never held across other products;
+    //   * the entry's coordinates come from `src`, BOTH AT THE TOP (one memory latency; for the GLS loop a table read plus
+    //     psi^h) and are dead after the second and the fourth product;
     //   * Z3 = (Z1 + H)^2 - Z1Z1 - HH is taken as soon as HH exists, which retires Z1 and Z1Z1 before J, V and the results;
     //   * the exceptional cases (p = O, q = +-p) are decided from two flags taken when H and rh exist and REBUILT FROM THE ENTRY
-    //     at the single join (q = p means 2p = 2q, q being affine), so p's coordinates die as the formula consumes them.
+    //     (src.x_again(), src.y_again(): re-read on the rare path) at the single join (q = p means 2p = 2q, q being affine), so
+    //     neither p's nor the entry's coordinates stay alive for them.
     // At most seven elements are alive at any call (X Y Zc Z1Z1 H rh + HH), six from there on.
     template <class Src>
     PTAU_HD static LazyJac2 add_src(const LazyJac2 &p, const Src &src) {
+        const AX x2 = src.x();
+        const AY y2 = src.y();
         const bool pinf = p.is_inf();
         const auto Z1Z1 = K::sqr(p.Zc);
-        const auto H = K::norm(K::sub(K::mul(src.x(), Z1Z1), p.X));                      // <1, 6>
-        const auto rh = K::norm(K::sub(K::mul(K::mul(src.y(), p.Zc), Z1Z1), p.Y));       // <1, 6>
+        const auto H = K::norm(K::sub(K::mul(x2, Z1Z1), p.X));                      // <1, 6>
+        const auto rh = K::norm(K::sub(K::mul(K::mul(y2, p.Zc), Z1Z1), p.Y));       // <1, 6>
         const bool hz = K::is_zero(H), rz = K::is_zero(rh);   // pair-uniform
         const auto HH = K::sqr(H);
         LazyJac2 r;
@@ -667,7 +681,7 @@ struct LazyJac2 {
         r.X = K::reduce(K::sub(R2, K::add(J, K::template times<2>(Vv))));
         r.Y = K::reduce(K::sub(K::mul(K::template times<2>(rh), K::sub(Vv, r.X)), K::template times<2>(K::mul(p.Y, J))));
         if (pinf || hz) {   // one join, rare paths, everything rebuilt from the entry
-            const LazyJac2 q = {K::reduce(src.x()), K::reduce(src.y()), K::one()};
+            const LazyJac2 q = {K::reduce(src.x_again()), K::reduce(src.y_again()), K::one()};
             if (pinf) r = q;
             else if (rz) r = dbl(q);
             else r = infinity();

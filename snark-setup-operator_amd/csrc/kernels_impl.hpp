@@ -605,6 +605,8 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
                 }
                 PTAU_HD typename L::AX x() const { return coord(0); }
                 PTAU_HD typename L::AY y() const { return coord(1); }
+                PTAU_HD typename L::AX x_again() const { return coord(0); }
+                PTAU_HD typename L::AY y_again() const { return coord(1); }
             };
             AccT cur = {px, py, K::one()};
 #pragma nounroll
@@ -710,15 +712,14 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
     // acc += (+-) table entry `mag` (with the GLV endomorphism applied when `endo`): a mixed addition on an affine table
     auto add_entry = [&](AccT &acc, int mag, bool negate, bool endo, const auto &beta) {
         if constexpr (G::LAZY_LOOP) {
-            // the entry read WHERE THE ADDITION CONSUMES IT (add_src): x (times beta under the endomorphism: a literal of the
-            // carry-free field) and y (negated for a negative digit); volatile reads, so the loads stay between the product calls
+            // the entry: x (times beta under the endomorphism: a literal of the carry-free field) and y (negated for a negative
+            // digit), read ONCE at the top of the addition (add_src) and re-read only on its rare exceptional join
             using K = typename L::K;
             using KM = typename LoopAcc<G, true>::zc_type;
             struct Entry {
                 const uint32_t *w;
                 bool endo, negate;
-                PTAU_HD KM coord(int c) const {
-                    const volatile uint32_t *q = w + c * L::N;
+                PTAU_HD static KM coord(const uint32_t *q) {
                     KM v;
 #pragma unroll
                     for (int j = 0; j < L::N; j++) {
@@ -727,8 +728,7 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
                     }
                     return v;
                 }
-                PTAU_HD typename L::AX x() const {
-                    KM v = coord(0);
+                PTAU_HD typename L::AX xform(KM v) const {
                     if constexpr (!L::PAIR && J::CfgT::GLV_KIND != 0) {
                         if (endo) {
                             typename L::LZ::template E<1, 1> b;
@@ -742,20 +742,32 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
                     }
                     return v;
                 }
-                PTAU_HD typename L::AY y() const {
-                    const KM v = coord(1);
+                PTAU_HD typename L::AY yform(const KM &v) const {
                     typename L::AY r = v;
                     if (negate) r = K::neg(v);
                     return r;
                 }
+                KM x0, y0;   // as loaded at the top
+                PTAU_HD typename L::AX x() const { return xform(x0); }
+                PTAU_HD typename L::AY y() const { return yform(y0); }
+                PTAU_HD static KM coord_again(const uint32_t *q0) {   // volatile: not merged with the read at the top (x0 / y0 die early)
+                    const volatile uint32_t *q = q0;
+                    KM v;
+#pragma unroll
+                    for (int j = 0; j < L::N; j++) {
+                        if constexpr (L::PAIR) v.c.l[j] = q[j];
+                        else v.l[j] = q[j];
+                    }
+                    return v;
+                }
+                PTAU_HD typename L::AX x_again() const { return xform(coord_again(w)); }
+                PTAU_HD typename L::AY y_again() const { return yform(coord_again(w + L::N)); }
             };
             const uint32_t *w = reinterpret_cast<const uint32_t *>(&wtab[(uint64_t)(mag - 1) * nslots + slot]);
-            uint32_t any = 0;   // (0, 0) marks a multiple that is O: OR of the entry's limbs, over the lanes of the point
-#pragma unroll
-            for (int j = 0; j < 2 * L::N; j++) any |= w[j];
-            if (L::all_lanes(any == 0)) return;
+            const Entry ent{w, endo, negate, Entry::coord(w), Entry::coord(w + L::N)};
+            if (L::all_lanes(K::limbs_all_zero_local(ent.x0) && K::limbs_all_zero_local(ent.y0))) return;   // (0, 0) marks a multiple that is O
             (void)beta;
-            acc = AccT::add_src(acc, Entry{w, endo, negate});
+            acc = AccT::add_src(acc, ent);
         } else if constexpr (G::AFFINE_TABLE) {
             const J *t = &wtab[(uint64_t)(mag - 1) * nslots + slot];
             A q;
@@ -878,20 +890,23 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
                     if (dgt != 0) {
                         const int mag = dgt < 0 ? -dgt : dgt;
                         if constexpr (G::LAZY_LOOP) {
-                            // psi^h of the table entry, formed WHERE THE ADDITION CONSUMES IT (LazyJac2::add_src): conjugate for
-                            // odd h, then one Fq constant per coordinate; volatile reads so that the loads are not hoisted above
-                            // the product calls in between (a coordinate held across them is a spill)
+                            // psi^h of the table entry: conjugate for odd h, then one Fq constant per coordinate; both coordinates are
+                            // read at the top (one memory latency), transformed where LazyJac2::add_src takes them and re-read only on
+                            // its rare exceptional join
                             using K = typename L::K;
                             using KM = typename LoopAcc<G, true>::zc_type;
                             struct GlsEntry {
                                 const uint32_t *tw;
                                 int h;
                                 bool negate;
-                                PTAU_HD KM coord(int c) const {
-                                    const volatile uint32_t *w = tw + c * L::N;
+                                KM x0, y0;
+                                PTAU_HD static KM load(const uint32_t *q) {
                                     KM v;
 #pragma unroll
-                                    for (int j = 0; j < L::N; j++) v.c.l[j] = w[j];
+                                    for (int j = 0; j < L::N; j++) v.c.l[j] = q[j];
+                                    return v;
+                                }
+                                PTAU_HD KM psi(KM v, int c) const {
                                     if (h) {
                                         typename L::LZ::template E<1, 1> k;
 #pragma unroll
@@ -902,19 +917,27 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
                                     }
                                     return v;
                                 }
-                                PTAU_HD typename L::AX x() const { return coord(0); }
-                                PTAU_HD typename L::AY y() const {
-                                    const KM v = coord(1);
+                                PTAU_HD typename L::AY ysign(const KM &v) const {
                                     typename L::AY r = v;
                                     if (negate) r = K::neg(v);
                                     return r;
                                 }
+                                PTAU_HD typename L::AX x() const { return psi(x0, 0); }
+                                PTAU_HD typename L::AY y() const { return ysign(psi(y0, 1)); }
+                                PTAU_HD static KM load_again(const uint32_t *q0) {   // volatile: not merged with the read at the top
+                                    const volatile uint32_t *q = q0;
+                                    KM v;
+#pragma unroll
+                                    for (int j = 0; j < L::N; j++) v.c.l[j] = q[j];
+                                    return v;
+                                }
+                                PTAU_HD typename L::AX x_again() const { return psi(load_again(tw), 0); }
+                                PTAU_HD typename L::AY y_again() const { return ysign(psi(load_again(tw + L::N), 1)); }
                             };
                             const uint32_t *tw = reinterpret_cast<const uint32_t *>(&wtab[(uint64_t)(mag - 1) * nslots + slot]);
-                            uint32_t any = 0;   // (0, 0) marks a multiple that is O: OR of the entry's 2 N limbs, both lanes
-#pragma unroll
-                            for (int j = 0; j < 2 * L::N; j++) any |= tw[j];
-                            if (!L::all_lanes(any == 0)) acc = AccT::add_src(acc, GlsEntry{tw, h, dgt < 0});
+                            const GlsEntry ent{tw, h, dgt < 0, GlsEntry::load(tw), GlsEntry::load(tw + L::N)};
+                            // (0, 0) marks a multiple that is O
+                            if (!L::all_lanes(K::limbs_all_zero_local(ent.x0) && K::limbs_all_zero_local(ent.y0))) acc = AccT::add_src(acc, ent);
                         } else {
                         J ent = wtab[(uint64_t)(mag - 1) * nslots + slot];   // affine table: Z slot unused (real common Z)
                         if (h) {
