@@ -989,8 +989,8 @@ int enqueue_subgroup_kernels(DeviceCtx *c, int curve, int group, const GroupOps 
                                        ptau::ScalarSource{ptau::SCALAR_SUBGROUP_ENDO, nullptr, 0, 0, 0}, 0, /*use_glv=*/1, d_err);
             else
                 ops->window_scalar_mul(st, d_in + off * isz, cin, scratch, wtab, m,
-                                       ptau::ScalarSource{ptau::SCALAR_FIXED, d_table, 0, 0, 0}, 0, /*use_glv=*/0, d_err);
-            if (via_psi) ops->psi_check(st, d_in + off * isz, cin, scratch, m, d_err);
+                                       ptau::ScalarSource{via_psi ? ptau::SCALAR_FIXED_PSI : ptau::SCALAR_FIXED, d_table, 0, 0, 0}, 0, /*use_glv=*/0, d_err);
+            if (via_psi) ops->psi_check(st, d_in + off * isz, cin, scratch, m, d_err);   // (nothing to launch when K1 compared in-kernel)
             else ops->expect_infinity(st, scratch, m, d_err);
         }
     }
@@ -1216,7 +1216,7 @@ int enqueue_single_side(DeviceCtx *c, int curve, int group, const GroupOps *ops,
                                            ptau::ScalarSource{ptau::SCALAR_SUBGROUP_ENDO, nullptr, 0, 0, 0}, 0, /*use_glv=*/1, d_err);
                 else
                     ops->window_scalar_mul(c->side_stream, b + SB_OUT, 0, b + SB_SCRATCH, b + SB_SCRATCH + ops->jac_bytes, 1,
-                                           ptau::ScalarSource{ptau::SCALAR_FIXED, (const uint32_t *)(b + SB_ORDER), 0, 0, 0}, 0, /*use_glv=*/0, d_err);
+                                           ptau::ScalarSource{via_psi ? ptau::SCALAR_FIXED_PSI : ptau::SCALAR_FIXED, (const uint32_t *)(b + SB_ORDER), 0, 0, 0}, 0, /*use_glv=*/0, d_err);
                 if (via_psi) ops->psi_check(c->side_stream, b + SB_OUT, 0, b + SB_SCRATCH, 1, d_err);
                 else ops->expect_infinity(c->side_stream, b + SB_SCRATCH, 1, d_err);
             }

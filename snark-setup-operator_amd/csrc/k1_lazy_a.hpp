@@ -311,11 +311,28 @@ __device__ inline int window_scalar_mul_lazy_a_thread(const uint8_t *__restrict_
             if (!K::limbs_all_zero(ent.z())) acc = Acc::add(acc, ent);   // the multiple is not O
         }
     }
+    int verdict = 0;
+    if constexpr (LG::HAS_GLS) {
+        // The psi membership test, compared HERE (SCALAR_FIXED_PSI: the scalar was |t - 1|): P is in the order-r subgroup iff
+        // psi(P) == [t - 1]P, i.e. (+-psi(P)) == [|t - 1|]P = acc.  +-psi(P) is FromTablePsi of entry 0 (P itself, Z = 1: the sign of
+        // t - 1 sits in the Y constants), affine; equality with the Jacobian acc by cross-multiplication — 2 squares' worth of
+        // tower products per point instead of a second, single-lane kernel over Fq2 / Fq3 by reference (round 3:
+        // psi_check_kernel<Mnt6G2>, 9.5 KB of scratch per lane, 21.6 ms for 68 waves).
+        if (src.mode == SCALAR_FIXED_PSI) {
+            const FromTablePsi q{entry(0), false};
+            const bool ainf = acc.is_inf();
+            const auto ZZ = K::sqr(acc.Zc);
+            const auto dx = K::norm(K::sub(K::mul(q.x(), ZZ), acc.X));
+            const auto dy = K::norm(K::sub(K::mul(K::mul(q.y(), acc.Zc), ZZ), acc.Y));
+            const bool same = K::is_zero(dx) && K::is_zero(dy);
+            if (ainf || !same) verdict = ERRBIT_NOT_IN_SUBGROUP;
+        }
+    }
     // ---- back to the reduced field, standard layout ----
     put29(Z::to29(K::raw(acc.X)), 0);
     put29(Z::to29(K::raw(acc.Y)), 1);
     put29(Z::to29(K::raw(acc.Zc)), 2);
-    return 0;
+    return verdict;
 }
 
 template <class LG>
@@ -326,6 +343,100 @@ window_scalar_mul_lazy_a_kernel(const uint8_t *__restrict__ in, uint32_t *__rest
     if (!lazy_a_point<LG>(n, i)) return;
     const int bad = window_scalar_mul_lazy_a_thread<LG>(in, scratch, wtab, n, i, src, check_input, use_gls);
     if (bad) atomicOr(err, bad);
+}
+
+// ---- K4 on the a != 0 twists: the accumulate pass of the bucket MSM (msm_accumulate_thread, kernels_impl.hpp) with one lane
+// pair per tower coefficient.  A run = run_len consecutive sorted entries, cut at bucket boundaries; the run's lanes (4 on
+// MNT4-753 G2, 6 on MNT6-753 G2) sum it by MIXED additions in the carry-free field.  Input: the standard affine array of the
+// single-lane group type (x coefficients | y coefficients, 26 limbs of 29 bits each, | flag word) — each pair reads ITS
+// coefficient's limbs and converts them with one base product per coordinate; output: partial sums in the standard Jacobian
+// layout (msm_combine of the single-lane type reads them).  Round 3 ran this pass in the reduced lane-split field with the
+// Fq2 / Fq3 point operations out of line by reference: msm_accumulate_kernel<Mnt6G2> 25 ms per vector at 40 % of wave cycles
+// waiting, 4.3 KB of scratch per lane (profiles/r03_pmc_cfg4.json).  Serves setup-utils' dense_multiexp inside
+// check_power_ratios — /root/reference/src/bin/verify_transcript.rs:812-822, contribute.rs:968-986.
+template <class LG>
+__device__ inline void msm_accumulate_lazy_a_thread(const uint32_t *__restrict__ aff, const uint32_t *__restrict__ sorted,
+                                                    const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ run_offsets,
+                                                    uint32_t *__restrict__ partials, uint32_t shift, uint32_t total_buckets, uint32_t v,
+                                                    uint32_t run_len) {
+    using K = typename LG::K;
+    using Z = typename LG::Z;
+    using Acc = typename LG::Acc;
+    using CT = typename LG::CT;
+    using L29 = typename LG::L29;
+    constexpr int D = LG::DEG;
+    constexpr uint32_t AFF_WORDS = 2 * D * LG::N29 + 1, JAC_WORDS = 3 * D * LG::N29;
+    const uint32_t total = offsets[total_buckets];
+    const uint64_t e0w = (uint64_t)v * run_len;
+    if (e0w >= total) return;
+    const uint32_t e0 = (uint32_t)e0w, e1 = e0w + run_len < total ? e0 + run_len : total;
+    uint32_t lo = 0, hi_b = total_buckets;   // largest b with offsets[b] <= e0: the (non-empty) bucket holding entry e0
+    while (hi_b - lo > 1) {
+        const uint32_t mid = (lo + hi_b) >> 1;
+        if (offsets[mid] <= e0) lo = mid; else hi_b = mid;
+    }
+    uint32_t b = lo, bend = offsets[b + 1];
+    const uint32_t mine = K::coef() * LG::N29 + (lane_parity() ? LG::H29 : 0);   // this lane's limbs inside a coordinate
+    auto store = [&](uint32_t bb, const Acc &acc) {
+        uint32_t *res = partials + (uint64_t)(run_offsets[bb] + (v - offsets[bb] / run_len)) * JAC_WORDS + mine;
+        const L29 x = Z::to29(K::raw(acc.X)), y = Z::to29(K::raw(acc.Y)), z = Z::to29(K::raw(acc.Zc));
+#pragma unroll
+        for (int t = 0; t < LG::H29; t++) {
+            res[t] = x.l[t];
+            res[D * LG::N29 + t] = y.l[t];
+            res[2 * D * LG::N29 + t] = z.l[t];
+        }
+    };
+    struct Entry {   // one affine point of the input vector, this pair's coefficient of x and y in the carry-free field
+        const uint32_t *w;   // this lane's limbs of x
+        bool negate;
+        PTAU_HD static CT conv(const uint32_t *q) {
+            L29 c;
+#pragma unroll
+            for (int t = 0; t < LG::H29; t++) c.l[t] = q[t];
+            return K::wrap(Z::from29(c));
+        }
+        PTAU_HD static CT conv_again(const uint32_t *q0) {   // volatile: not merged with the read at the top
+            const volatile uint32_t *q = q0;
+            L29 c;
+#pragma unroll
+            for (int t = 0; t < LG::H29; t++) c.l[t] = q[t];
+            return K::wrap(Z::from29(c));
+        }
+        PTAU_HD auto sign(const CT &yv) const {
+            const auto nv = K::neg(yv);
+            decltype(K::neg(yv)) r = yv;
+            if (negate) r = nv;
+            return r;
+        }
+        PTAU_HD CT x() const { return conv(w); }
+        PTAU_HD auto y() const { return sign(conv(w + D * LG::N29)); }
+        PTAU_HD CT x_again() const { return conv_again(w); }
+        PTAU_HD auto y_again() const { return sign(conv_again(w + D * LG::N29)); }
+    };
+    Acc acc = Acc::infinity();
+    for (uint32_t e = e0; e < e1; e++) {
+        if (e == bend) {   // the next bucket starts here
+            store(b, acc);
+            acc = Acc::infinity();
+            do { b++; bend = offsets[b + 1]; } while (bend <= e);
+        }
+        const uint32_t s = sorted[e];
+        const uint32_t *w = aff + ((uint64_t)(s & 0x7fffffffu) + shift) * AFF_WORDS;
+        if (w[2 * D * LG::N29] & 0xffu) continue;   // the point at infinity (bool flag in the word's low byte)
+        acc = Acc::add_affine(acc, Entry{w + mine, (s >> 31) != 0});
+    }
+    store(b, acc);
+}
+
+template <class LG>
+__global__ void __launch_bounds__(256, 2)
+msm_accumulate_lazy_a_kernel(const uint32_t *__restrict__ aff, const uint32_t *__restrict__ sorted, const uint32_t *__restrict__ offsets,
+                             const uint32_t *__restrict__ run_offsets, uint32_t *__restrict__ partials, uint32_t shift,
+                             uint32_t total_buckets, uint64_t max_runs, uint32_t run_len) {
+    uint64_t v;
+    if (!lazy_a_point<LG>(max_runs, v)) return;
+    msm_accumulate_lazy_a_thread<LG>(aff, sorted, offsets, run_offsets, partials, shift, total_buckets, (uint32_t)v, run_len);
 }
 
 }  // namespace ptau

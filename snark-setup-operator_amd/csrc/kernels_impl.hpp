@@ -197,7 +197,9 @@ scalar_mul_kernel(const uint8_t *__restrict__ in, int compressed_in, typename G:
 // Where a thread's scalar comes from.
 // SCALAR_SUBGROUP_ENDO: no scalar at all — the two fixed half-length multipliers (a, b) of the endomorphism membership test
 // [a]P + [b]phi(P) == O (lattice-GLV curves: BW6-761; gen_constants.py SUB_A / SUB_B), through the GLV window loop
-enum : int { SCALAR_TAU_TABLE = 0, SCALAR_FIXED = 1, SCALAR_ARRAY = 2, SCALAR_PRF = 3, SCALAR_SUBGROUP_ENDO = 4 };
+// SCALAR_FIXED_PSI: SCALAR_FIXED with the scalar |t - 1| of the psi membership test (MNT twists); a kernel that can compares
+// its result with psi(P) itself (k1_lazy_a.hpp) and Launch::psi_check then launches nothing
+enum : int { SCALAR_TAU_TABLE = 0, SCALAR_FIXED = 1, SCALAR_ARRAY = 2, SCALAR_PRF = 3, SCALAR_SUBGROUP_ENDO = 4, SCALAR_FIXED_PSI = 5 };
 struct ScalarSource {
     int mode;
     const uint32_t *ptr;      // TAU_TABLE: the tau^(2^k) table; FIXED: NL canonical limbs; ARRAY: n x NL canonical limbs
@@ -252,7 +254,7 @@ constexpr int PRF_MAX_BITS = 200;
 template <class Fr>
 PTAU_HD void thread_scalar(const ScalarSource &src, uint64_t i, uint32_t (&k)[Fr::N]) {
     constexpr int NL = Fr::N;
-    if (src.mode == SCALAR_FIXED) {          // one public scalar for every point (subgroup check: the group order)
+    if (src.mode == SCALAR_FIXED || src.mode == SCALAR_FIXED_PSI) {   // one public scalar for every point (subgroup check)
 #pragma unroll
         for (int j = 0; j < NL; j++) k[j] = src.ptr[j];
     } else if (src.mode == SCALAR_ARRAY) {   // explicit per-point scalars (MSM with caller-supplied coefficients)
@@ -536,6 +538,15 @@ struct LazyOf {
     }
 };
 
+// The same address as far as the hardware goes, a NEW one as far as the optimiser goes: a re-read through it is not merged
+// with an earlier read of the same words (whose registers may then die early) and stays where it is written.
+PTAU_HD const uint32_t *reread_ptr(const uint32_t *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(p));
+#endif
+    return p;
+}
+
 template <class G, bool LAZY>
 struct LoopAcc {
     using type = typename G::J;
@@ -591,10 +602,10 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
             const typename L::C px = L::to_lazy(p.x), py = L::to_lazy(p.y);
             L::store(w0, px);
             L::store(w0 + L::N, py);
-            struct ParkedP {   // (x, y) of P from entry 0's slot; volatile: the reads stay where the formula uses them
+            struct ParkedP {   // (x, y) of P from entry 0's slot, re-read for every addition (never held in registers across them)
                 const uint32_t *w;
                 PTAU_HD typename L::C coord(int c) const {
-                    const volatile uint32_t *q = w + c * L::N;
+                    const uint32_t *q = reread_ptr(w + c * L::N);
                     typename L::C v;
 #pragma unroll
                     for (int j = 0; j < L::N; j++) {
@@ -750,16 +761,7 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
                 KM x0, y0;   // as loaded at the top
                 PTAU_HD typename L::AX x() const { return xform(x0); }
                 PTAU_HD typename L::AY y() const { return yform(y0); }
-                PTAU_HD static KM coord_again(const uint32_t *q0) {   // volatile: not merged with the read at the top (x0 / y0 die early)
-                    const volatile uint32_t *q = q0;
-                    KM v;
-#pragma unroll
-                    for (int j = 0; j < L::N; j++) {
-                        if constexpr (L::PAIR) v.c.l[j] = q[j];
-                        else v.l[j] = q[j];
-                    }
-                    return v;
-                }
+                PTAU_HD static KM coord_again(const uint32_t *q0) { return coord(reread_ptr(q0)); }   // not merged with the read at the top
                 PTAU_HD typename L::AX x_again() const { return xform(coord_again(w)); }
                 PTAU_HD typename L::AY y_again() const { return yform(coord_again(w + L::N)); }
             };
@@ -767,7 +769,17 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
             const Entry ent{w, endo, negate, Entry::coord(w), Entry::coord(w + L::N)};
             if (L::all_lanes(K::limbs_all_zero_local(ent.x0) && K::limbs_all_zero_local(ent.y0))) return;   // (0, 0) marks a multiple that is O
             (void)beta;
-            acc = AccT::add_src(acc, ent);
+            if constexpr (L::PAIR) {
+                // BLS12-377 G2, plain windows (BatchExpMode::Direct, the fallback of Auto): the entry stays in registers for the
+                // rare join as well.  With the re-reading form of the join this kernel returned wrong sums for POSITIVE digits after
+                // the first addition (tests/test_gpu_verify.py::test_direct_windows_on_structured_scalars; the GLS loop's identical
+                // construction is right) — the generated code differs only in that join; not understood, avoided here.
+                const typename L::AX ex = ent.x();
+                const typename L::AY ey = ent.y();
+                acc = AccT::add_mixed(acc, ex, ey);
+            } else {
+                acc = AccT::add_src(acc, ent);
+            }
         } else if constexpr (G::AFFINE_TABLE) {
             const J *t = &wtab[(uint64_t)(mag - 1) * nslots + slot];
             A q;
@@ -924,13 +936,7 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
                                 }
                                 PTAU_HD typename L::AX x() const { return psi(x0, 0); }
                                 PTAU_HD typename L::AY y() const { return ysign(psi(y0, 1)); }
-                                PTAU_HD static KM load_again(const uint32_t *q0) {   // volatile: not merged with the read at the top
-                                    const volatile uint32_t *q = q0;
-                                    KM v;
-#pragma unroll
-                                    for (int j = 0; j < L::N; j++) v.c.l[j] = q[j];
-                                    return v;
-                                }
+                                PTAU_HD static KM load_again(const uint32_t *q0) { return load(reread_ptr(q0)); }   // not merged with the read at the top
                                 PTAU_HD typename L::AX x_again() const { return psi(load_again(tw), 0); }
                                 PTAU_HD typename L::AY y_again() const { return ysign(psi(load_again(tw + L::N), 1)); }
                             };
@@ -1958,6 +1964,7 @@ struct Launch {
                 return;
             }
         }
+        if (src.mode == SCALAR_FIXED_PSI) src.mode = SCALAR_FIXED;   // the kernels below leave the comparison to psi_check_kernel
         if constexpr (!std::is_void_v<GL>) {
             if (!cin && lane_pair_enabled()) {   // two threads per point; results land in G's Jacobian layout
                 hipLaunchKernelGGL((window_scalar_mul_kernel<GL, 0>), grid(n * 2), dim3(256), 0, s, in, (typename GL::J *)scratch,
@@ -1992,6 +1999,18 @@ struct Launch {
     static void msm_accumulate(hipStream_t s, const void *aff, const uint32_t *sorted, const uint32_t *offsets,
                                const uint32_t *run_offsets, void *partials, uint32_t shift, uint32_t total_buckets, uint64_t max_runs,
                                uint32_t run_len) {
+        if constexpr (!std::is_void_v<GA>) {
+            if constexpr (GA::DEG >= 2) {   // the twists of the a != 0 curves: one lane pair per tower coefficient (k1_lazy_a.hpp)
+                static_assert(sizeof(typename G::A) == (2 * GA::DEG * GA::N29 + 1) * 4 && sizeof(typename G::J) == 3 * GA::DEG * GA::N29 * 4,
+                              "standard affine / Jacobian layouts");
+                if (lazy_a_enabled()) {
+                    const uint64_t blocks = (max_runs + GA::POINTS_PER_BLOCK - 1) / GA::POINTS_PER_BLOCK;
+                    hipLaunchKernelGGL(msm_accumulate_lazy_a_kernel<GA>, dim3((unsigned)blocks), dim3(256), 0, s, (const uint32_t *)aff, sorted,
+                                       offsets, run_offsets, (uint32_t *)partials, shift, total_buckets, max_runs, run_len);
+                    return;
+                }
+            }
+        }
         if constexpr (!std::is_void_v<GL>) {
             static_assert(sizeof(typename G::A) == (2 * G::F::DEG * G::Fq::N + 1) * 4 || G::Fq::LB != 29, "standard affine layout");
             if (lane_pair_enabled()) {   // two threads per run; affine input and Jacobian partials in G's layouts
@@ -2056,6 +2075,9 @@ struct Launch {
     static void psi_check(hipStream_t s, const uint8_t *in, int cin, const void *scratch, uint64_t n, int *err) {
         if constexpr (G::J::CfgT::PSI_KIND == 1) {
             if (!n) return;
+            if constexpr (!std::is_void_v<GA>) {
+                if (!cin && lazy_a_enabled()) return;   // window_scalar_mul (SCALAR_FIXED_PSI) compared in the kernel
+            }
             hipLaunchKernelGGL(psi_check_kernel<G>, grid(n), dim3(256), 0, s, in, cin, (const typename G::J *)scratch, n, err);
         }
     }
@@ -2094,6 +2116,11 @@ struct Launch {
         o.msm_accumulate = msm_accumulate;
         o.msm_lanes_per_run = 1;
         if constexpr (!std::is_void_v<GL>) o.msm_lanes_per_run = GL::LPP;
+        if constexpr (!std::is_void_v<GA>) {
+            if constexpr (GA::DEG >= 2) {
+                if (lazy_a_enabled()) o.msm_lanes_per_run = GA::LPP;
+            }
+        }
         o.msm_combine = msm_combine;
         o.msm_bucket_reduce = msm_bucket_reduce;
         o.reduce_rows = reduce_rows;

@@ -582,6 +582,36 @@ struct LazyJacA {
         }
         return r;
     }
+
+    // madd-2007-bl with Z3 = 2 Z1 H (7M + 4S): the second operand AFFINE (a point of the MSM's input vector), read ONCE by the
+    // caller at the top (src.x(), src.y()) and re-read only on the rare exceptional join (src.x_again(), src.y_again()), so
+    // neither its nor p's coordinates stay alive for that join; at most seven field elements are alive at any product call
+    // (the same ordering as LazyJac2::add_src, fpz.hpp).  The formula does not involve the curve's a.
+    template <class Src>
+    PTAU_HD static LazyJacA add_affine(const LazyJacA &p, const Src &src) {
+        const auto x2 = src.x();
+        const auto y2 = src.y();
+        const bool pinf = p.is_inf();
+        const auto Z1Z1 = K::sqr(p.Zc);
+        const auto Hh = K::norm(K::sub(K::mul(x2, Z1Z1), p.X));
+        const auto rh = K::norm(K::sub(K::mul(K::mul(y2, p.Zc), Z1Z1), p.Y));
+        const bool hz = K::is_zero(Hh), rz = K::is_zero(rh);
+        LazyJacA r;
+        r.Zc = K::norm(K::template times<2>(K::mul(p.Zc, Hh)));
+        const auto I = K::template times<4>(K::sqr(Hh));   // (2 H)^2 as 4 H^2: H carries p.X's bound, 2 H would exceed the square's
+        const auto J = K::mul(Hh, I);
+        const auto Vv = K::mul(p.X, I);
+        const auto R2 = K::template times<4>(K::sqr(rh));  // (2 rh)^2
+        r.X = K::norm(K::sub(R2, K::add(J, K::template times<2>(Vv))));
+        r.Y = K::norm(K::sub(K::mul(K::template times<2>(rh), K::sub(Vv, r.X)), K::template times<2>(K::mul(p.Y, J))));
+        if (pinf || hz) {   // one join, rare paths, everything rebuilt from the entry
+            const LazyJacA q = {src.x_again(), K::mul(K::norm(src.y_again()), K::one()), K::one()};
+            if (pinf) r = q;
+            else if (rz) r = dbl(q);
+            else r = infinity();
+        }
+        return r;
+    }
 };
 
 }  // namespace ptau

@@ -653,3 +653,22 @@ def test_auto_probe_batched_on_long_vectors(name, group, pkg, cref):
     # ... and an infinity element is a legal input when nobody asked for non-zero elements: same bytes on both paths
     assert pkg.phase1_cli.apply_powers(name, group, bytes(inf), n, 11, tau, coeff, False, True, batch_exp_mode=pkg.BatchExpMode.Auto) == \
         pkg.phase1_cli.apply_powers(name, group, bytes(inf), n, 11, tau, coeff, False, True, batch_exp_mode=pkg.BatchExpMode.Direct)
+
+
+@pytest.mark.parametrize("name,group", [(c, g) for c in ("bls12_377", "bw6", "mnt4_753", "mnt6_753") for g in (1, 2)])
+def test_direct_windows_on_structured_scalars(name, group, pkg):
+    """K1's window loops on scalars whose signed 4-bit digits are chosen, not random: a positive digit after the first addition
+    (0x11, 0x21, 0x7777), a negative one (0x1f, 0x9999), single digits, the top of the range — [k]G for 64 copies of a point
+    through BatchExpMode::Direct (plain windows) and through the endomorphism loops (membership asserted), against the Python
+    oracle's scalar multiplication.  Round 4 found the BLS12-377 G2 plain-window kernel wrong on exactly the first pattern while
+    every random-scalar parity test passed through the GLS loop; this pins each loop's digit handling on every group."""
+    c = CURVES[name]
+    G = Group(c, group)
+    csz = G.comp_size
+    gen = serde.write_point(G, G.gen, False)
+    n = 64
+    for k in (1, 7, 8, 9, 0x10, 0x11, 0x12, 0x1f, 0x21, 0x88, 0x89, 0x111, 0x7777, 0x9999, 0xfedcba9876543210, c.r - 1, c.r - 2, c.r // 3):
+        want = serde.write_point(G, G.mul(G.gen, k), True)
+        for mode in (pkg.BatchExpMode.Direct, int(pkg.BatchExpMode.Auto) | pkg.phase1_cli.INPUT_IN_SUBGROUP):
+            got = pkg.phase1_cli.apply_powers(name, group, gen * n, n, 0, 1, k, False, True, batch_exp_mode=mode)
+            assert got == want * n, (name, group, hex(k), int(mode))
