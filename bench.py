@@ -421,7 +421,27 @@ def macs_per_update(curve, group, endo):
     return (4 * windows - 4) * dbl + (windows * 15 // 16 + 7) * add + io
 
 
-def pmc_for(tag, config):
+def sqrt_macs(curve="bls12_377"):
+    """32x32->64 multiply-accumulates of ONE base-field square root as decompress_kernel runs it (fp29.hpp sqrt_ex; BLS12-377 Fq,
+    13 limbs of 29 bits, fully reduced: product 325, square 247 MACs in the ISA): a^((T-1)/2) by sliding 4-bit windows over the
+    330-bit exponent (329 squares + 66 products + an 8-entry table: 1 + 7), x = a w and b = x w (2 products), the Pohlig-Hellman
+    stage in the 2^46 torsion on ONE squaring chain (37 squares + 20 products for the windows' corrections + 5 for g^-d;
+    round 3: 111 squares + 12 products), the root (1 product) and its check (1 square)."""
+    assert curve == "bls12_377"
+    m, sq = 325, 247
+    return (329 + 1 + 37 + 1) * sq + (66 + 7 + 2 + 25 + 1) * m
+
+
+def decompress_macs_per_chunk(n):
+    """decompress_kernel over a 2^20 BLS12-377 chunk: 3 n G1 elements (one square root, x^3 + b, Montgomery conversions and the
+    sign: ~6 products more) and n + 1 G2 elements (complex method: the norm, sqrt(norm), then sqrt_or_nr of (a0 + alpha) / 2 — one
+    exponentiation serves both candidates, the torsion stage runs twice for half the elements — and ~25 products of glue)."""
+    g1 = sqrt_macs() + 6 * 325
+    g2 = 2 * sqrt_macs() + (37 * 247 + 25 * 325) // 2 + 25 * 325
+    return 3 * n * g1 + (n + 1) * g2
+
+
+def pmc_for(tag, config, prefix="window_scalar_mul"):
     """Counters of window_scalar_mul*kernel<tag> from the rocprofv3 PMC summary of THIS config and the NEWEST round that has one
     (profiles/rNN_pmc_cfg<config>.json, written by tools/gpu_round.sh before the bench line is taken).  No fallback to
     another config's file: a summary that lacks the kernel yields None."""
@@ -438,7 +458,7 @@ def pmc_for(tag, config):
         except Exception:
             continue
         for name, d in k.items():
-            if name.startswith("window_scalar_mul") and ("<%s>" % tag) in name and "hbm_bytes_per_launch" in d:
+            if name.startswith(prefix) and ("<%s>" % tag) in name and "hbm_bytes_per_launch" in d:
                 best = (d, os.path.basename(f))
     return best if best else (None, None)
 
@@ -1011,6 +1031,11 @@ def bench_verify(args, pkg, dev, rank, world, dist, backend, barrier):
             elems = 4 * n + 1
             dec_s = dec_ms / args.steps / 1e3
             algo = 3 * n * (48 + 96) + (n + 1) * (96 + 192)      # decompression: compressed element in, uncompressed element out
+            dmacs = decompress_macs_per_chunk(n)
+            p1, src1 = pmc_for("BlsG1", 5, "decompress_kernel")
+            p2, _ = pmc_for("BlsG2", 5, "decompress_kernel")
+            # PMC traffic of the four decompression launches of one chunk (3 G1 vectors + the G2 vector; the lone beta_g2 launch is noise)
+            dtraffic = (3 * p1["hbm_bytes_per_launch"] + p2["hbm_bytes_per_launch"]) if (p1 and p2 and lg == 20) else None
             print(json.dumps({
                 "metric": "chunks verified/sec", "value": world * args.steps / dt, "unit": "chunks verified/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -1028,8 +1053,13 @@ def bench_verify(args, pkg, dev, rank, world, dist, backend, barrier):
                 "device_busy_frac_per_rank": busy,
                 "roofline": {"bound": "hbm", "kernel": "decompress_kernel (G1 x3 vectors + G2)", "kernel_ms": dec_ms / args.steps,
                              "achieved": algo / dec_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo / dec_s / 1e9 / HBM_PEAK_GBS,
-                             "traffic": None, "note": "a square root is ~575 field products per coordinate (331-bit exponentiation + "
-                                                      "Pohlig-Hellman in the 2^46 torsion): integer-ALU-bound, see DESIGN.md"},
+                             "traffic": dtraffic, "traffic_source": src1, "traffic_ratio": (dtraffic / algo) if dtraffic else None,
+                             "algorithmic_bytes_per_chunk": algo, "macs_per_chunk": dmacs, "alu_peak_mac_per_s": MAC_PEAK,
+                             "alu_frac": dmacs / dec_s / MAC_PEAK,
+                             "note": "a square root is ~470 field products per coordinate (330-bit exponentiation + Pohlig-Hellman in the "
+                                     "2^46 torsion on one squaring chain): integer-ALU-bound; alu_frac = modelled 32x32->64 MACs (bench.py "
+                                     "sqrt_macs / decompress_macs_per_chunk) over the measured v_mad_u64_u32 issue peak; traffic = PMC bytes of "
+                                     "the chunk's four decompression launches (the 80 KB torsion table is gathered per lane), DESIGN.md §4.4"},
                 "sharded_transform_ratios": sharded,
                 "cpu_baseline": cpu_verify_baseline(lg) if world == 1 else None}))
     finally:
