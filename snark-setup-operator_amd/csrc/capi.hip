@@ -267,7 +267,9 @@ int ensure_ctx(int device, DeviceCtx *&c, const Err &err, bool side = false) {
     // vector kernels and copies normal.  The side context (contribute's beta_g2) only ever uses its main and copy streams.
     int prio_least = 0, prio_greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) { (void)hipGetLastError(); prio_least = prio_greatest = 0; }
-    const int prio[5] = {0, prio_least, 0, prio_least, prio_greatest};   // main, side, copy, pair, tail
+    // PTAU_TAIL_PRIO=normal: the tail stream at the main stream's priority (A/B runs)
+    const char *tp = getenv("PTAU_TAIL_PRIO");
+    const int prio[5] = {0, prio_least, 0, prio_least, (tp && tp[0] == 'n') ? 0 : prio_greatest};   // main, side, copy, pair, tail
     for (int i = 0; i < 5 && e == hipSuccess; i++) {
         if (side && i != 0 && i != 2) continue;
         e = hipStreamCreateWithPriority(&st[i], hipStreamNonBlocking, std::min(std::max(prio[i], prio_greatest), prio_least));

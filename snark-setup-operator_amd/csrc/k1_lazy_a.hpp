@@ -439,4 +439,136 @@ msm_accumulate_lazy_a_kernel(const uint32_t *__restrict__ aff, const uint32_t *_
     msm_accumulate_lazy_a_thread<LG>(aff, sorted, offsets, run_offsets, partials, shift, total_buckets, (uint32_t)v, run_len);
 }
 
+// ---- the small kernels behind the bucket sums (msm_combine / msm_bucket_reduce / reduce_rows / msm_horner / reduce_sum of
+// kernels_impl.hpp), same algorithms, one lane pair per tower coefficient.  They run a few hundred to a few thousand threads
+// of SEQUENTIAL Jacobian additions each — on a 2^16-point chunk of an MNT twist this latency chain (on the tail stream, with the
+// bucket tests) outlasts the main stream's work; in the reduced field by reference an Fq3 addition is ~100 base products
+// through 9 KB of scratch in one lane, here it is inlined register-ABI products over six.  Points travel in the standard
+// Jacobian layout of the single-lane group type (26 limbs of 29 bits per coefficient): three converting products in, three out.
+template <class LG>
+struct LazyAStd {
+    using K = typename LG::K;
+    using Z = typename LG::Z;
+    using Acc = typename LG::Acc;
+    using CT = typename LG::CT;
+    using L29 = typename LG::L29;
+    static constexpr int D = LG::DEG;
+    static constexpr uint32_t JAC_WORDS = 3 * D * LG::N29;
+    __device__ static uint32_t mine() { return K::coef() * LG::N29 + (lane_parity() ? LG::H29 : 0); }
+    __device__ static CT coord(const uint32_t *q) {
+        L29 c;
+#pragma unroll
+        for (int t = 0; t < LG::H29; t++) c.l[t] = q[t];
+        return K::wrap(Z::from29(c));
+    }
+    __device__ static Acc load(const uint32_t *base, uint64_t idx) {
+        const uint32_t *w = base + idx * JAC_WORDS + mine();
+        return {coord(w), coord(w + D * LG::N29), coord(w + 2 * D * LG::N29)};
+    }
+    __device__ static void store(uint32_t *base, uint64_t idx, const Acc &a) {
+        uint32_t *res = base + idx * JAC_WORDS + mine();
+        const L29 x = Z::to29(K::raw(a.X)), y = Z::to29(K::raw(a.Y)), z = Z::to29(K::raw(a.Zc));
+#pragma unroll
+        for (int t = 0; t < LG::H29; t++) {
+            res[t] = x.l[t];
+            res[D * LG::N29 + t] = y.l[t];
+            res[2 * D * LG::N29 + t] = z.l[t];
+        }
+    }
+    struct Regs {   // a Jacobian point held in registers as the second operand of LazyJacA::add
+        const CT &x_, &y_, &z_;
+        PTAU_HD CT x() const { return x_; }
+        PTAU_HD CT y() const { return y_; }
+        PTAU_HD CT z() const { return z_; }
+    };
+    __device__ static Acc add(const Acc &p, const Acc &q) {   // either operand may be the point at infinity
+        if (q.is_inf()) return p;                               // (uniform over the point's lanes)
+        return Acc::add(p, Regs{q.X, q.Y, q.Zc});
+    }
+};
+
+template <class LG>
+__global__ void __launch_bounds__(256, 2)
+msm_combine_lazy_a_kernel(const uint32_t *__restrict__ partials, const uint32_t *__restrict__ run_offsets, uint32_t *__restrict__ buckets,
+                          uint64_t total_buckets) {
+    using S = LazyAStd<LG>;
+    uint64_t t;
+    if (!lazy_a_point<LG>(total_buckets, t)) return;
+    typename S::Acc acc = S::Acc::infinity();
+    const uint32_t v1 = run_offsets[t + 1];
+    for (uint32_t v = run_offsets[t]; v < v1; v++) acc = S::add(acc, S::load(partials, v));
+    S::store(buckets, t, acc);
+}
+
+// thread (w, s): sum_{b in segment s} (b + 1) * bucket[w][b]  =  sum of running sums + lo * (segment sum)
+template <class LG>
+__global__ void __launch_bounds__(256, 2)
+msm_bucket_reduce_lazy_a_kernel(const uint32_t *__restrict__ buckets, uint32_t *__restrict__ parts, MsmPlan pl, uint64_t total) {
+    using S = LazyAStd<LG>;
+    using Acc = typename S::Acc;
+    uint64_t t;
+    if (!lazy_a_point<LG>(total, t)) return;
+    const uint32_t nseg = pl.B / pl.seg;
+    const uint32_t w = (uint32_t)(t / nseg), sg = (uint32_t)(t % nseg), lo = sg * pl.seg;
+    const uint64_t base = (uint64_t)w * pl.B;
+    Acc run = Acc::infinity(), tot = Acc::infinity();
+    for (uint32_t b = lo + pl.seg; b-- > lo;) {
+        run = S::add(run, S::load(buckets, base + b));
+        tot = S::add(tot, run);
+    }
+    if (lo) {   // + lo * run, MSB-first double-and-add over the (<= 16) bits of lo
+        Acc acc = Acc::infinity();
+        for (int bit = 31 - __builtin_clz(lo); bit >= 0; bit--) {
+            acc = Acc::dbl(acc);
+            if ((lo >> bit) & 1u) acc = S::add(acc, run);
+        }
+        tot = S::add(tot, acc);
+    }
+    S::store(parts, t, tot);
+}
+
+// rows x cols -> rows x T: thread (r, t) sums in[r][t], in[r][t + T], ...
+template <class LG>
+__global__ void __launch_bounds__(256, 2)
+reduce_rows_lazy_a_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint32_t cols, uint32_t T, uint64_t total) {
+    using S = LazyAStd<LG>;
+    uint64_t id;
+    if (!lazy_a_point<LG>(total, id)) return;
+    const uint64_t r = id / T, t = id % T;
+    typename S::Acc acc = S::Acc::infinity();
+    for (uint64_t j = t; j < cols; j += T) acc = S::add(acc, S::load(in, r * cols + j));
+    S::store(out, id, acc);
+}
+
+// sum_w 2^(c w) win[w]: one point's lanes per sum (block b = sum b)
+// (256-thread bounds like every kernel of this file although one point's lanes work: a kernel compiled for one wave per SIMD
+// would let the shared product routines use AGPRs, and a callee's register count is every caller's — K1 dropped to one wave)
+template <class LG>
+__global__ void __launch_bounds__(256, 2)
+msm_horner_lazy_a_kernel(const uint32_t *__restrict__ win, uint32_t *__restrict__ out, MsmPlan pl, uint64_t out_stride) {
+    using S = LazyAStd<LG>;
+    using Acc = typename S::Acc;
+    if (threadIdx.x >= (unsigned)LG::LPP) return;
+    const uint64_t wbase = (uint64_t)blockIdx.x * pl.W;
+    Acc acc = Acc::infinity();
+    for (int w = pl.W - 1; w >= 0; w--) {
+        if (!acc.is_inf())
+            for (int d = 0; d < pl.c; d++) acc = Acc::dbl(acc);
+        acc = S::add(acc, S::load(win, wbase + w));
+    }
+    S::store(out, (uint64_t)blockIdx.x * out_stride, acc);
+}
+
+// thread t adds elements t, t + T, t + 2T, ... (< n) into out[t]
+template <class LG>
+__global__ void __launch_bounds__(256, 2)
+reduce_sum_lazy_a_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint64_t n, uint64_t T) {
+    using S = LazyAStd<LG>;
+    uint64_t t;
+    if (!lazy_a_point<LG>(T, t)) return;
+    typename S::Acc acc = S::Acc::infinity();
+    for (uint64_t i = t; i < n; i += T) acc = S::add(acc, S::load(in, i));
+    S::store(out, t, acc);
+}
+
 }  // namespace ptau

@@ -1988,6 +1988,12 @@ struct Launch {
     }
     static void reduce_sum(hipStream_t s, const void *in, void *out, uint64_t n, uint64_t T) {
         if (!T) return;
+        if constexpr (lazy_a_tails()) {
+            if (lazy_a_enabled()) {
+                hipLaunchKernelGGL(reduce_sum_lazy_a_kernel<GA>, ga_grid(T), dim3(256), 0, s, (const uint32_t *)in, (uint32_t *)out, n, T);
+                return;
+            }
+        }
         hipLaunchKernelGGL(reduce_sum_kernel<G>, grid(T), dim3(256), 0, s, (const typename G::J *)in, (typename G::J *)out, n, T);
     }
     static void msm_prepare(hipStream_t s, const uint8_t *in, int cin, void *aff, uint32_t *dig, uint32_t *counts,
@@ -2022,20 +2028,52 @@ struct Launch {
         hipLaunchKernelGGL(msm_accumulate_kernel<G>, grid(max_runs), dim3(256), 0, s, (const typename G::A *)aff, sorted,
                            offsets, run_offsets, (typename G::J *)partials, shift, total_buckets, run_len);
     }
+    // the small kernels behind the bucket sums on the twists of the a != 0 curves: one lane pair per tower coefficient
+    static constexpr bool lazy_a_tails() {
+        if constexpr (!std::is_void_v<GA>) return GA::DEG >= 2;
+        else return false;
+    }
+    template <class T = GA>
+    static dim3 ga_grid(uint64_t threads) { return dim3((unsigned)((threads + T::POINTS_PER_BLOCK - 1) / T::POINTS_PER_BLOCK)); }
     static void msm_combine(hipStream_t s, const void *partials, const uint32_t *run_offsets, void *buckets, uint64_t total_buckets) {
+        if constexpr (lazy_a_tails()) {
+            if (lazy_a_enabled()) {
+                hipLaunchKernelGGL(msm_combine_lazy_a_kernel<GA>, ga_grid(total_buckets), dim3(256), 0, s, (const uint32_t *)partials, run_offsets,
+                                   (uint32_t *)buckets, total_buckets);
+                return;
+            }
+        }
         hipLaunchKernelGGL(msm_combine_kernel<G>, grid(total_buckets), dim3(256), 0, s, (const typename G::J *)partials,
                            run_offsets, (typename G::J *)buckets, total_buckets);
     }
     static void msm_bucket_reduce(hipStream_t s, const void *buckets, void *parts, MsmPlan pl, uint64_t total) {
+        if constexpr (lazy_a_tails()) {
+            if (lazy_a_enabled()) {
+                hipLaunchKernelGGL(msm_bucket_reduce_lazy_a_kernel<GA>, ga_grid(total), dim3(256), 0, s, (const uint32_t *)buckets, (uint32_t *)parts, pl, total);
+                return;
+            }
+        }
         hipLaunchKernelGGL(msm_bucket_reduce_kernel<G>, grid(total), dim3(256), 0, s, (const typename G::J *)buckets,
                            (typename G::J *)parts, pl, total);
     }
     static void reduce_rows(hipStream_t s, const void *in, void *out, uint32_t rows, uint32_t cols, uint32_t T) {
         const uint64_t total = (uint64_t)rows * T;
+        if constexpr (lazy_a_tails()) {
+            if (lazy_a_enabled()) {
+                hipLaunchKernelGGL(reduce_rows_lazy_a_kernel<GA>, ga_grid(total), dim3(256), 0, s, (const uint32_t *)in, (uint32_t *)out, cols, T, total);
+                return;
+            }
+        }
         hipLaunchKernelGGL(reduce_rows_kernel<G>, grid(total), dim3(256), 0, s, (const typename G::J *)in, (typename G::J *)out,
                            cols, T, total);
     }
     static void msm_horner(hipStream_t s, const void *win, void *out, MsmPlan pl, int nsum, uint64_t out_stride) {
+        if constexpr (lazy_a_tails()) {
+            if (lazy_a_enabled()) {
+                hipLaunchKernelGGL(msm_horner_lazy_a_kernel<GA>, dim3(nsum), dim3(64), 0, s, (const uint32_t *)win, (uint32_t *)out, pl, out_stride);
+                return;
+            }
+        }
         hipLaunchKernelGGL(msm_horner_kernel<G>, dim3(nsum), dim3(64), 0, s, (const typename G::J *)win, (typename G::J *)out, pl,
                            out_stride);
     }
