@@ -545,7 +545,13 @@ def launch_ranks(world, argv, script=None, popen=None, timeout=None):
                 except Exception:
                     pass
     if out0:
-        sys.stdout.write(out0.decode(errors="replace"))
+        # rank 0's ONE JSON line goes to stdout; anything else a library printed there (gloo's "[Gloo] Rank 0 is connected ...")
+        # is passed on through stderr, so that stdout stays the one line the contract promises
+        for line in out0.decode(errors="replace").splitlines():
+            if line.lstrip().startswith("{"):
+                sys.stdout.write(line + "\n")
+            elif line.strip():
+                sys.stderr.write(line + "\n")
         sys.stdout.flush()
     return rc
 
