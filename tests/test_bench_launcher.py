@@ -66,3 +66,33 @@ def test_parent_does_not_import_torch_before_spawning(tmp_path):
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert "TORCH_IN_PARENT False" in p.stdout, p.stdout + p.stderr
     assert "RC 0" not in p.stdout          # no GPU here: the ranks fail and the parent says so
+
+
+def test_only_json_lines_of_rank0_reach_stdout(tmp_path, capfd):
+    """A library of rank 0 may print to stdout before the line (gloo: "[Gloo] Rank 0 is connected ..."): the parent passes such
+    lines on through stderr, stdout stays the ONE JSON line the contract promises."""
+    b = _bench()
+    script = tmp_path / "child.py"
+    script.write_text('import json, os\nif os.environ["RANK"] == "0":\n    print("[Gloo] Rank 0 is connected to 1 peer ranks.")\n'
+                      '    print(json.dumps({"metric": "m", "value": 1}))\n')
+    rc = b.launch_ranks(2, [], script=str(script), timeout=60)
+    out, err = capfd.readouterr()
+    assert rc == 0
+    assert out.strip().splitlines() == ['{"metric": "m", "value": 1}'] and "[Gloo]" in err
+
+
+def test_workdir_with_room_or_a_clean_error(tmp_path, monkeypatch):
+    """The file-level measurements map hundreds of megabytes per lane: pick_workdir returns a directory on a file system with
+    the room (tmpfs first), and stops with a message — not a SIGBUS inside an mmap'd write — when nothing has it."""
+    import shutil
+    b = _bench()
+    d, base = b.pick_workdir(1 << 20, "ptau_test_")
+    try:
+        assert os.path.isdir(d) and os.path.dirname(d) == base
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    import pytest
+    with pytest.raises(SystemExit) as e:
+        b.pick_workdir(1 << 62, "ptau_test_")
+    assert "scratch space" in str(e.value) and "GB free" in str(e.value)
+    assert 1 <= b.host_cpu_share() <= (os.cpu_count() or 1)
