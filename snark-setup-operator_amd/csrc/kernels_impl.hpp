@@ -1877,9 +1877,10 @@ struct GroupOps {
     bool membership_cheap;
     // the group has an endomorphism-accelerated multiplication at all (GLV / GLS; use_glv of window_scalar_mul is honoured)
     bool has_endo_mul;
-    // ... and the batched membership probe of BatchExpMode::Auto costs less than the endomorphism saves.  Not on the MNT4-753
-    // twist: its 2^16-point probe (16 ms of bucket sums in the single-lane Fq2 + the psi tests beside K1) and the GLS saving
-    // (13 ms) cancel — 0.57 against 0.59 M updates/s measured; MNT6-753 G2 gains 18 %, BW6-761 8 %, BLS12-377 17 % / 49 %
+    // ... and the batched membership probe of BatchExpMode::Auto costs less than the endomorphism saves: BLS12-377 17 % / 49 %,
+    // BW6-761 8 %, MNT6-753 G2 18 %; on the MNT4-753 twist since round 4 (bucket sums and their tails in the lane-pair-per-
+    // coefficient field, the psi comparison inside K1: probe 8.9 ms + GLS 92 ms beside its tests against 112 ms plain, +7 %;
+    // in round 3 the 16 ms probe and the 13 ms saving cancelled)
     bool auto_probe_pays;
     // membership through psi (MNT twists): K1 with the fixed scalar psi_scalar (fr_limbs32 words), then psi_check on its result
     const uint32_t *psi_scalar;
@@ -1908,6 +1909,13 @@ template <class GL, int MODE>
 constexpr bool twin_is() {
     if constexpr (std::is_void_v<GL>) return false;
     else return GL::LANE_MODE == MODE;
+}
+inline bool probe_pays_on_mnt4_twist() {
+    static const bool v = [] {
+        const char *e = getenv("PTAU_AUTO_PROBE_MNT4");
+        return !(e && e[0] == '0');
+    }();
+    return v;
 }
 // PTAU_LAZY_A=0 keeps the a != 0 groups on the round-2 kernels (reduced field, pair layout): A/B runs.
 inline bool lazy_a_enabled() {
@@ -2172,7 +2180,8 @@ struct Launch {
         o.membership_cheap = G::J::CfgT::ENDO_KIND == 2 && Fr::N == 8;
         o.has_endo_mul = G::J::CfgT::GLV_KIND != 0 || (G::J::CfgT::ENDO_KIND == 2 && Fr::N == 8);
         if constexpr (!std::is_void_v<GA>) o.has_endo_mul = o.has_endo_mul || GA::HAS_GLS;
-        o.auto_probe_pays = o.has_endo_mul && !(G::J::CfgT::PSI_KIND == 1 && G::F::DEG == 2);
+        // PTAU_AUTO_PROBE_MNT4=0 restores the round-3 choice (no probe on the MNT4-753 twist) for A/B runs
+        o.auto_probe_pays = o.has_endo_mul && (!(G::J::CfgT::PSI_KIND == 1 && G::F::DEG == 2) || probe_pays_on_mnt4_twist());
         if constexpr (G::J::CfgT::PSI_KIND == 1) {
             static_assert(sizeof(G::J::CfgT::PSI_N) / 4 == Fr::N, "psi scalar must have the scalar field's word count");
             o.psi_scalar = G::J::CfgT::PSI_N;

@@ -596,7 +596,7 @@ def test_batched_subgroup_check_through_the_msm_buckets(name, pkg):
     assert nc[:64] == pkg.calculate_hash(bytes(resp))
 
 
-@pytest.mark.parametrize("name,group", [("bls12_377", 1), ("bls12_377", 2), ("bw6", 1), ("mnt6_753", 2)])
+@pytest.mark.parametrize("name,group", [("bls12_377", 1), ("bls12_377", 2), ("bw6", 1), ("mnt4_753", 2), ("mnt6_753", 2)])
 def test_auto_probe_batched_on_long_vectors(name, group, pkg, cref):
     """BatchExpMode::Auto on more than 2^12 unchecked elements probes the vector with the batched membership test (random
     bucket sums, each tested exactly; capi.hip run_batched_subgroup_dev) and takes the endomorphism path only when it passes.
