@@ -801,7 +801,7 @@ typedef struct {
     int cin, cout;
     u64 lo, hi, start;
     const u64 *tau, *coeff;
-    int rc;
+    int rc, joinable;
 } ap_job;
 
 static void *apply_powers_worker(void *arg) {
@@ -852,12 +852,14 @@ int oracle_apply_powers(int curve_id, int grp, const uint8_t *in, int cin, uint8
         J->C = C; J->G = &C->g[grp - 1]; J->in = in; J->out = out; J->cin = cin; J->cout = cout;
         J->lo = n * t / nthreads; J->hi = n * (t + 1) / nthreads; J->start = start;
         J->tau = tau; J->coeff = coeff; J->rc = 0;
-        if (nthreads == 1) apply_powers_worker(J);
-        else pthread_create(&th[t], NULL, apply_powers_worker, J);
+        /* a thread that cannot be created (a box's thread cap) must not leave its slice unwritten: run it here */
+        J->joinable = 0;
+        if (nthreads == 1 || pthread_create(&th[t], NULL, apply_powers_worker, J) != 0) apply_powers_worker(J);
+        else J->joinable = 1;
     }
     int rc = 0;
     for (int t = 0; t < nthreads; t++) {
-        if (nthreads > 1) pthread_join(th[t], NULL);
+        if (jobs[t].joinable) pthread_join(th[t], NULL);
         if (jobs[t].rc) rc = jobs[t].rc;
     }
     return rc;
@@ -894,7 +896,7 @@ typedef struct {
     const uint8_t *in;
     uint8_t *out;
     u64 lo, hi;
-    int rc;
+    int rc, joinable;
 } dc_job;
 static void *decompress_worker(void *arg) {
     dc_job *J = (dc_job *)arg;
@@ -918,12 +920,13 @@ int oracle_decompress(int curve_id, int grp, const uint8_t *in, uint8_t *out, ui
         dc_job *J = &jobs[t];
         J->C = C; J->G = &C->g[grp - 1]; J->in = in; J->out = out;
         J->lo = n * t / nthreads; J->hi = n * (t + 1) / nthreads; J->rc = 0;
-        if (nthreads == 1) decompress_worker(J);
-        else pthread_create(&th[t], NULL, decompress_worker, J);
+        J->joinable = 0;
+        if (nthreads == 1 || pthread_create(&th[t], NULL, decompress_worker, J) != 0) decompress_worker(J);
+        else J->joinable = 1;
     }
     int rc = 0;
     for (int t = 0; t < nthreads; t++) {
-        if (nthreads > 1) pthread_join(th[t], NULL);
+        if (jobs[t].joinable) pthread_join(th[t], NULL);
         if (jobs[t].rc) rc = jobs[t].rc;
     }
     return rc;

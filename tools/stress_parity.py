@@ -16,7 +16,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 rng = random.Random(2026)
 n_arg = n
 # the MNT groups (round 3: carry-free lane-per-coefficient kernels, GLS on the twists) at sizes the CPU oracle finishes in seconds
-for name, group, div in (("bls12_377", 1, 1), ("bls12_377", 2, 1), ("bw6", 1, 1), ("bw6", 2, 1), ("mnt4_753", 1, 8), ("mnt6_753", 1, 8),
+for name, group, div in (("bls12_377", 1, 1), ("bls12_377", 2, 1)) if os.environ.get("STRESS_ONLY_BLS") else (("bls12_377", 1, 1), ("bls12_377", 2, 1), ("bw6", 1, 1), ("bw6", 2, 1), ("mnt4_753", 1, 8), ("mnt6_753", 1, 8),
                          ("mnt4_753", 2, 16), ("mnt6_753", 2, 32)):
     n = max(64, n_arg // div)
     c = CURVES[name]; G = Group(c, group); F = G.F
@@ -45,5 +45,13 @@ for name, group, div in (("bls12_377", 1, 1), ("bls12_377", 2, 1), ("bw6", 1, 1)
             got = pkg.phase1_cli.apply_powers(name, group, data, n, start, tau, coeff, False, True, batch_exp_mode=mode)
             bad = 0 if got == exp else sum(1 for i in range(n) if got[i * G.comp_size:(i + 1) * G.comp_size] != exp[i * G.comp_size:(i + 1) * G.comp_size])
             print(name, group, tag, "mode", int(mode), "mismatches", bad, "of", n, "(oracle %.1f s)" % t_cpu, flush=True)
+            if bad:   # say WHICH side is off: both are recomputed once (a CPU-side or a GPU-side fluke shows as a result that changes)
+                idx = [i for i in range(n) if got[i * G.comp_size:(i + 1) * G.comp_size] != exp[i * G.comp_size:(i + 1) * G.comp_size]]
+                print("   first mismatches", idx[:10], "last", idx[-5:], "flags of first bad input", data[(idx[0] + 1) * G.uncomp_size - 1], flush=True)
+                exp2 = cref.apply_powers(name, group, data, n, start, tau, coeff, False, True, nthreads=16)
+                got2 = pkg.phase1_cli.apply_powers(name, group, data, n, start, tau, coeff, False, True, batch_exp_mode=mode)
+                exp1 = cref.apply_powers(name, group, data, n, start, tau, coeff, False, True, nthreads=1) if n <= 65536 else None
+                print("   recomputed: oracle same as before:", exp2 == exp, "| GPU same as before:", got2 == got, "| GPU(2) == oracle(2):", got2 == exp2,
+                      "| oracle 1 thread == 16 threads:", None if exp1 is None else exp1 == exp2, flush=True)
             assert bad == 0
 print("stress parity ok")
