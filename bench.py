@@ -441,6 +441,17 @@ def decompress_macs_per_chunk(n):
     return 3 * n * g1 + (n + 1) * g2
 
 
+def msm_accumulate_macs_per_chunk(n, windows=11):
+    """msm_accumulate_kernel over the four power_pairs reductions of a 2^20 BLS12-377 chunk verification: every point lands in one
+    bucket per window (signed 13-bit digits of a 142-bit coefficient: 11 windows; a 2^-13 share of zero digits ignored) in BOTH
+    sums (the vector and its shift), one mixed addition each — G1 (one lane, FpZ): 8 products + 3 squares; G2 (lane pair,
+    fused two-term products): 7 Fq2 products + 4 Fq2 squares + the two converting products per coordinate and lane."""
+    zm, zs, zm2 = 378, 287, 574
+    g1 = 8 * zm + 3 * zs
+    g2 = 7 * 2 * zm2 + 4 * 2 * zm + 2 * 2 * zm
+    return 2 * windows * (3 * n * g1 + n * g2)
+
+
 def pmc_for(tag, config, prefix="window_scalar_mul"):
     """Counters of window_scalar_mul*kernel<tag> from the rocprofv3 PMC summary of THIS config and the NEWEST round that has one
     (profiles/rNN_pmc_cfg<config>.json, written by tools/gpu_round.sh before the bench line is taken).  No fallback to
@@ -1066,6 +1077,12 @@ def bench_verify(args, pkg, dev, rank, world, dist, backend, barrier):
                                      "2^46 torsion on one squaring chain): integer-ALU-bound; alu_frac = modelled 32x32->64 MACs (bench.py "
                                      "sqrt_macs / decompress_macs_per_chunk) over the measured v_mad_u64_u32 issue peak; traffic = PMC bytes of "
                                      "the chunk's four decompression launches (the 80 KB torsion table is gathered per lane), DESIGN.md §4.4"},
+                "msm": {"kernel": "msm_accumulate_kernel (3 G1 vectors + G2, two sums each) inside msm_ms", "msm_ms": msm_ms / args.steps,
+                        "accumulate_macs_per_chunk": msm_accumulate_macs_per_chunk(n),
+                        "alu_frac_lower_bound": msm_accumulate_macs_per_chunk(n) / (msm_ms / args.steps / 1e3) / MAC_PEAK,
+                        "note": "msm_ms also holds msm_prepare, the counting sort, msm_combine and what of the tails was not hidden: the "
+                                "accumulate launches alone are 29 of its 44 ms (profiles/r04_verify_timeline.txt), i.e. alu_frac ~0.59 — "
+                                "random gathers of 116-byte points, one exposed latency per addition"},
                 "sharded_transform_ratios": sharded,
                 "cpu_baseline": cpu_verify_baseline(lg) if world == 1 else None}))
     finally:
