@@ -5,6 +5,8 @@
 // The hot instruction is v_mad_u64_u32 (32x32+64 -> 64); limbs live in VGPRs, every loop is
 // unrolled at compile time so no limb array is ever runtime-indexed (no scratch).
 #pragma once
+#include <type_traits>
+#include <utility>
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
@@ -75,6 +77,23 @@ PTAU_HD void acc_shift(Acc96 &a) {
 // in a local array (private memory; the index is the same in every lane) — about top_bit / 5 + 8 products instead of one
 // per set bit (the square roots' exponents are dense: 377- and 753-bit exponents cost ~85 / ~160 products instead of
 // ~165 / ~376).
+// k squarings in a row: ONE call where the field has a chained form (Fp29::sqr_n: the limbs stay in the callee's registers
+// between squarings, no marshalling / call / wait per squaring), a loop of squarings elsewhere
+template <class F, class = void>
+struct HasSqrN : std::false_type {};
+template <class F>
+struct HasSqrN<F, std::void_t<decltype(F::sqr_n(std::declval<const F &>(), 0))>> : std::true_type {};
+template <class F>
+PTAU_HD F sqr_times(const F &a, int k) {
+    if constexpr (HasSqrN<F>::value) {
+        return k > 0 ? F::sqr_n(a, k) : a;
+    } else {
+        F r = a;
+        for (int i = 0; i < k; i++) r = F::sqr(r);
+        return r;
+    }
+}
+
 template <class F>
 PTAU_HD F pow_sliding(const F &a, const uint32_t *e, int top_bit) {
     F tab[8];
@@ -84,10 +103,10 @@ PTAU_HD F pow_sliding(const F &a, const uint32_t *e, int top_bit) {
     auto bit = [&](int i) -> uint32_t { return (e[i >> 5] >> (i & 31)) & 1u; };
     F r = F::one();
     bool started = false;
-    int i = top_bit;
+    int i = top_bit, pend = 0;   // pend: squarings owed to r (zero bits and the window's width), paid in one chained call
     while (i >= 0) {
         if (!bit(i)) {
-            if (started) r = F::sqr(r);
+            if (started) pend++;
             i--;
             continue;
         }
@@ -96,7 +115,8 @@ PTAU_HD F pow_sliding(const F &a, const uint32_t *e, int top_bit) {
         uint32_t val = 0;
         for (int k = i; k >= j; k--) val = (val << 1) | bit(k);
         if (started) {
-            for (int k = i; k >= j; k--) r = F::sqr(r);
+            r = sqr_times(r, pend + (i - j + 1));
+            pend = 0;
             r = F::mul(r, tab[val >> 1]);
         } else {
             r = tab[val >> 1];
@@ -104,7 +124,7 @@ PTAU_HD F pow_sliding(const F &a, const uint32_t *e, int top_bit) {
         }
         i = j - 1;
     }
-    return r;
+    return sqr_times(r, pend);
 }
 
 template <class P>

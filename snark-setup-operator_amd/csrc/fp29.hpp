@@ -210,6 +210,24 @@ struct Fp29 {
         for (int i = 0; i < N; i++) o[i] = r[i];
         return o;
     }
+    // k squarings in a row in ONE call (square roots: runs of squarings between the window products of the exponentiation, the
+    // 37-step chain of the torsion stage): the limbs stay in registers between squarings — no argument marshalling, call,
+    // entry wait and return per squaring (~40 of a squaring's ~450 instructions)
+    __host__ __device__ __noinline__ static VecN sqr_n_vec(VecN a, int k) {
+        uint32_t x[N], r[N];
+#pragma unroll
+        for (int i = 0; i < N; i++) x[i] = a[i];
+#pragma nounroll
+        for (int t = 0; t < k; t++) {
+            ps_mul<true>(x, x, r);
+#pragma unroll
+            for (int i = 0; i < N; i++) x[i] = r[i];
+        }
+        VecN o;
+#pragma unroll
+        for (int i = 0; i < N; i++) o[i] = x[i];
+        return o;
+    }
     __host__ __device__ __noinline__ static Fp29 mul_out(const Fp29 &a, const Fp29 &b) { return mul_inl(a, b); }
     __host__ __device__ __noinline__ static Fp29 sqr_out(const Fp29 &a) { return sqr_inl(a); }
     // -DPTAU_INLINE_MUL13 inlines the 13-limb product at every call site: measured +3.5 % on K1 (32.3 vs 31.2 M updates/s)
@@ -247,6 +265,18 @@ struct Fp29 {
             for (int i = 0; i < N; i++) r.l[i] = o[i];
             return r;
         }
+    }
+
+    template <bool ENABLE = !MUL_OUT_OF_LINE>
+    PTAU_HD static std::enable_if_t<ENABLE, Fp29> sqr_n(const Fp29 &a, int k) {   // a^(2^k); only where the register ABI serves the field
+        VecN x;
+#pragma unroll
+        for (int i = 0; i < N; i++) x[i] = a.l[i];
+        const VecN o = sqr_n_vec(x, k);
+        Fp29 r;
+#pragma unroll
+        for (int i = 0; i < N; i++) r.l[i] = o[i];
+        return r;
     }
 
     // k * a for a small positive constant (4 <= k <= 7 when p fills its top limb: k p's top limb must fit 32 bits; up to 15
@@ -420,7 +450,8 @@ struct Fp29 {
 #pragma unroll
                 for (int j = L - 1; j >= 0; j--) {
                     const int sh = E - W * j - wj_of(j);
-                    for (; s < sh; s++) t = sqr(t);
+                    t = sqr_times(t, sh - s);
+                    s = sh;
                     c[j] = t;
                 }
             }

@@ -459,6 +459,37 @@ struct FpL {
         for (int j = 0; j < H; j++) o[j] = r[j];
         return o;
     }
+    // k squarings in a row in ONE call (the square roots' exponentiations: fp.hpp sqr_times)
+    __device__ __noinline__ static VecH sqr_n_vec(VecH a, int k) {
+        uint32_t x[H], r[H];
+#pragma unroll
+        for (int j = 0; j < H; j++) x[j] = a[j];
+#pragma nounroll
+        for (int t = 0; t < k; t++) {
+            row_sqr(x, r);
+#pragma unroll
+            for (int j = 0; j < H; j++) x[j] = r[j];
+        }
+        VecH o;
+#pragma unroll
+        for (int j = 0; j < H; j++) o[j] = x[j];
+        return o;
+    }
+    PTAU_HD static FpL sqr_n(const FpL &a, int k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        VecH x;
+#pragma unroll
+        for (int j = 0; j < H; j++) x[j] = a.l[j];
+        const VecH o = sqr_n_vec(x, k);
+        FpL r;
+#pragma unroll
+        for (int j = 0; j < H; j++) r.l[j] = o[j];
+        return r;
+#else
+        (void)k;
+        return a;
+#endif
+    }
     PTAU_HD static FpL sqr(const FpL &a) {
 #if defined(__HIP_DEVICE_COMPILE__)
         VecH x;
@@ -594,7 +625,7 @@ struct FpL {
             const int wj = (E - W * j) < W ? (E - W * j) : W;
             const int sh = E - W * j - wj;
             FpL t = b;
-            for (int k = 0; k < sh; k++) t = sqr(t);
+            t = sqr_times(t, sh);
             const uint32_t lo = lane_bcast_even(t.l[0]);
             int K = -1;
             for (int k = 0; k < (1 << W); k++) K = (P::SQRT_ZLOW[k] == lo) ? k : K;
@@ -632,7 +663,7 @@ struct FpL {
                 const int wj = (E - W * j) < W ? (E - W * j) : W;
                 const int sh = E - W * j - wj;
                 FpL t = b;
-                for (int k = 0; k < sh; k++) t = sqr(t);
+                t = sqr_times(t, sh);
                 const uint32_t lo = lane_bcast_even(t.l[0]);
                 int K = -1;
                 for (int k = 0; k < (1 << W); k++) K = (P::SQRT_ZLOW[k] == lo) ? k : K;
