@@ -356,6 +356,7 @@ struct CallTiming {   // declare AFTER the lock guard: the destructor then reads
     int device;
     bool detached = false;
     ptau_timing mine = {};
+    CallTiming(DeviceCtx *ctx, int dev) : c(ctx), device(dev) { c->timing = ptau_timing{}; }   // (a call that fails before its first kernel reports zeros, not its predecessor's record)
     void detach() { mine = c->timing; detached = true; }   // under the lock, just before it is released
     ~CallTiming() { tl_timing[device] = detached ? mine : c->timing; }
 };
@@ -369,10 +370,14 @@ int claim_out_buffer(DeviceCtx *c, int sel, size_t need, void *&buf, const Err &
     void *&d = sel ? c->d_out_alt : c->d_out;
     size_t &cap = sel ? c->out_alt_cap : c->out_cap;
     if (c->buf_copying[sel]) {
-        if (cap < need) {
+        if (hipEventQuery(c->bufev[sel]) == hipSuccess) {   // the copy has landed long ago: nothing to order behind
+            c->buf_copying[sel] = false;
+        } else if (cap < need) {
+            (void)hipGetLastError();   // (hipErrorNotReady from the query is not an error)
             HIP_TRY(hipEventSynchronize(c->bufev[sel]));
             c->buf_copying[sel] = false;
         } else {
+            (void)hipGetLastError();
             HIP_TRY(hipStreamWaitEvent(c->stream, c->bufev[sel], 0));
         }
     }
@@ -648,7 +653,10 @@ int run_msm_bucket_dev(DeviceCtx *c, const GroupOps *ops, const uint8_t *d_in, i
     if (fuse && !(defer_tail && src.mode == ptau::SCALAR_PRF && (fuse->only ? !out_b : out_b != nullptr)))
         return err.fail(PTAU_E_ARG, "membership-fused MSM: wrong call form");
     const bool only = fuse && fuse->only;
-    const int test_cost = fuse ? std::max(1, ops->subgroup_cost_adds) : 0;
+    // PTAU_TEST_COST_SCALE=<x>: weight of one bucket test in the window-width choice, times x (A/B runs: fewer, larger buckets
+    // against more of them — the tests are latency-bound waves that hold SIMD slots beside whatever the main stream runs)
+    static const double test_cost_scale = [] { const char *e = getenv("PTAU_TEST_COST_SCALE"); const double v = e ? atof(e) : 1.0; return v > 0 ? v : 1.0; }();
+    const int test_cost = fuse ? std::max(1, (int)(ops->subgroup_cost_adds * test_cost_scale)) : 0;
     const uint64_t resident_runs = (uint64_t)std::max(1, c->cus) * 512 / ops->msm_lanes_per_run;
     if (c->cur->tail.active) {   // left behind by a call that failed: its results are of no interest, its kernels must be done
         HIP_TRY(hipEventSynchronize(c->cur->tev[2]));
