@@ -771,9 +771,13 @@ PTAU_HD int window_scalar_mul_thread(const uint8_t *in, int compressed_in, typen
             (void)beta;
             if constexpr (L::PAIR) {
                 // BLS12-377 G2, plain windows (BatchExpMode::Direct, the fallback of Auto): the entry stays in registers for the
-                // rare join as well.  With the re-reading form of the join this kernel returned wrong sums for POSITIVE digits after
-                // the first addition (tests/test_gpu_verify.py::test_direct_windows_on_structured_scalars; the GLS loop's identical
-                // construction is right) — the generated code differs only in that join; not understood, avoided here.
+                // rare join as well.  With the re-reading form ROCm 7.2's clang MISCOMPILES this kernel: the register allocator's
+                // copies of x0 land at the top of the join block of `if (negate)` in yform, AHEAD of that block's
+                // `s_or_b64 exec, exec, s[0:1]`, so they run under the branch's mask - for a positive digit under EXEC = 0, i.e.
+                // not at all, and every addition after the first (whose result comes from the join) used stale registers
+                // (tests/test_gpu_verify.py::test_direct_windows_on_structured_scalars).  Not a source error, and
+                // any other change of register pressure hides it, so the BUILD is gated instead: the Makefile disassembles
+                // every object and refuses that pattern (tools/isa_exec_prologue_check.py).  This form does not produce it.
                 const typename L::AX ex = ent.x();
                 const typename L::AY ey = ent.y();
                 acc = AccT::add_mixed(acc, ex, ey);

@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""Finds vector instructions placed ahead of the EXEC restore at a control-flow join.
+
+The AMDGPU backend ends a divergent `if` with `s_or_b64 exec, exec, <saved>` as the first instruction of the join block.
+Register-allocator copies (live-range splits) are inserted at the top of a block; when scalar moves already sit there the
+"block prologue" scan stops early and VECTOR copies land BEFORE the restore, so they execute under the mask of the branch
+that is ending - with a uniformly false condition (`s_cbranch_execz` taken) under EXEC = 0, i.e. not at all.  That is a
+miscompile (ROCm 7.2's clang did it to the BLS12-377 G2 plain-window kernel: DESIGN.md 4.4b) and it is invisible in the
+source, so the build is checked instead:
+
+    isa_exec_prologue_check.py file.s [...]         # hipcc -S --cuda-device-only output
+    isa_exec_prologue_check.py --object file.o [...] # a built object: the gfx950 code object is unbundled and disassembled
+                                                    # (clang-offload-bundler + llvm-objdump --symbolize-operands), so the
+                                                    # check sees the very code that ships (the Makefile does this per object)
+
+Reports every join block whose restore is preceded by VALU/VMEM instructions; exit status 1 when any is found.
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+LABEL = re.compile(r"^(?:[0-9a-f]{8,16} <([^>]+)>|(\.LBB\d+_\d+|_Z\w+|[A-Za-z_]\w*)):")   # objdump form | .s form
+SAVE = re.compile(r"\bs_and_saveexec_b64\s+(s\[\d+:\d+\])")
+SKIP = re.compile(r"\bs_cbranch_execz\s+(\.LBB\d+_\d+|L\d+)\b")
+BLOCK = re.compile(r"^(\.L\w+|L\d+)$")
+VECTOR = re.compile(r"^\s*(v_|global_|flat_|scratch_|buffer_|ds_)")
+ENDS = re.compile(r"^\s*(s_cbranch|s_branch|s_endpgm|s_setpc|s_swappc)")
+# vector instructions that do not depend on EXEC are harmless ahead of the restore
+EXEC_FREE = re.compile(r"^\s*(v_readlane_b32|v_readfirstlane_b32|v_writelane_b32)")
+
+
+def instructions(path):
+    with open(path, errors="replace") as f:
+        for ln, raw in enumerate(f, 1):
+            line = raw.split("//")[0].split(";")[0].rstrip()
+            if line.strip():
+                yield ln, line
+
+
+def label_of(line):
+    m = LABEL.match(line)
+    return (m.group(1) or m.group(2)) if m else None
+
+
+def check(path):
+    """-> [(function, label, line, [(line, text), ...])]"""
+    lines = list(instructions(path))
+    # the skip branch of every divergent if: (function, label) -> the SGPR pairs holding the mask to restore there
+    joins = {}
+    func = "?"
+    for i, (ln, line) in enumerate(lines):
+        name = label_of(line)
+        if name is not None and not BLOCK.match(name):
+            func = name
+        m = SAVE.search(line)
+        if not m:
+            continue
+        for _, nxt in lines[i + 1:i + 4]:
+            k = SKIP.search(nxt)
+            if k:
+                joins.setdefault((func, k.group(1)), set()).add(m.group(1))
+                break
+            if label_of(nxt) is not None or VECTOR.match(nxt):
+                break
+    found = []
+    func = "?"
+    for i, (ln, line) in enumerate(lines):
+        name = label_of(line)
+        if name is None:
+            continue
+        if not BLOCK.match(name):
+            func = name
+            continue
+        if (func, name) not in joins:
+            continue
+        restores = [re.compile(r"\bs_or_b64\s+exec,\s*exec,\s*" + re.escape(sg)) for sg in joins[(func, name)]]
+        pending = []
+        for l2, t in lines[i + 1:]:
+            if label_of(t) is not None or ENDS.match(t):
+                break                    # no restore in this block: the mask is restored further on (nested joins)
+            if any(r.search(t) for r in restores):
+                if pending:
+                    found.append((func, name, ln, pending))
+                break
+            if VECTOR.match(t) and not EXEC_FREE.match(t):
+                pending.append((l2, t.strip()))
+    return found
+
+
+LLVM_BIN = os.environ.get("LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+
+
+def disassemble(obj, out):
+    """The gfx950 code object bundled in a hipcc object -> out (text); False when the object has no device code."""
+    fat, co = out + ".fatbin", out + ".co"
+    subprocess.run([os.path.join(LLVM_BIN, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, obj, os.devnull],
+                   capture_output=True, text=True)
+    if not os.path.exists(fat):
+        return False                     # host-only object: nothing to check
+    r = subprocess.run([os.path.join(LLVM_BIN, "clang-offload-bundler"), "--unbundle", "--type=o",
+                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat, "--output=" + co],
+                       capture_output=True, text=True)
+    if r.returncode != 0 or not os.path.exists(co) or os.path.getsize(co) == 0:
+        raise RuntimeError(f"{obj}: no gfx950 code object in it ({r.stderr.strip()})")
+    with open(out, "w") as f:
+        subprocess.run([os.path.join(LLVM_BIN, "llvm-objdump"), "-d", "--symbolize-operands", co], stdout=f,
+                       stderr=subprocess.DEVNULL, check=True)
+    os.unlink(co)
+    os.unlink(fat)
+    return True
+
+
+def main(argv):
+    total = 0
+    objects = bool(argv) and argv[0] == "--object"
+    if objects:
+        argv = argv[1:]
+    if not argv:
+        print(__doc__)
+        return 2
+    for path in argv:
+        if objects:
+            with tempfile.TemporaryDirectory() as d:
+                text = os.path.join(d, "isa.s")
+                hits = check(text) if disassemble(path, text) else []
+        else:
+            hits = check(path)
+        for func, label, ln, ins in hits:
+            total += 1
+            print(f"{path}:{ln}: {func[:90]} block {label}: {len(ins)} vector instruction(s) before the EXEC restore")
+            for l, t in ins[:4]:
+                print(f"    {l}: {t}")
+    print(f"{total} suspicious join block(s)")
+    return 1 if total else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))
