@@ -64,6 +64,20 @@ BAD_OBJDUMP = """
 """
 
 
+FALLTHROUGH_BAD_S = """
+_Z6kernelv:
+	s_and_saveexec_b64 s[0:1], vcc
+; %bb.1:
+	v_sub_u32_e32 v43, 0x21a3fffe, v43
+; %bb.2:
+	s_mov_b32 s81, 0x29185f12
+	v_mov_b64_e32 v[102:103], v[2:3]
+	s_or_b64 exec, exec, s[0:1]
+	s_endpgm
+.Lfunc_end0:
+"""
+
+
 def run_on(tmp_path, text):
     p = tmp_path / "k.s"
     p.write_text(text)
@@ -82,6 +96,21 @@ def test_vector_copy_ahead_of_the_restore_is_found(tmp_path):
 def test_scalar_prologue_and_fallthrough_bodies_are_not_flagged(tmp_path):
     assert run_on(tmp_path, GOOD_S) == []
     assert isa_check.main([str(tmp_path / "k.s")]) == 0
+
+
+def test_join_without_a_skip_branch_is_checked_in_compiler_listings(tmp_path):
+    """A short body loses its `s_cbranch_execz`: the join has no label, only the listing's `; %bb.N:` shows it."""
+    p = tmp_path / "k.s"
+    p.write_text(FALLTHROUGH_BAD_S)
+    assert isa_check.check(str(p)) == []
+    hits = isa_check.check_fallthrough(str(p))
+    assert len(hits) == 1 and hits[0][3][0][1].startswith("v_mov_b64_e32")
+    assert isa_check.main([str(p)]) == 1
+    p.write_text(FALLTHROUGH_BAD_S.replace("\tv_mov_b64_e32 v[102:103], v[2:3]\n", ""))
+    assert isa_check.main([str(p)]) == 0
+    # body and join printed as one block (nothing can have been inserted between them): not flagged
+    p.write_text(FALLTHROUGH_BAD_S.replace("; %bb.2:\n", ""))
+    assert isa_check.main([str(p)]) == 0
 
 
 def test_objdump_listing_with_per_function_labels(tmp_path):

@@ -14,6 +14,11 @@ source, so the build is checked instead:
                                                     # check sees the very code that ships (the Makefile does this per object)
 
 Reports every join block whose restore is preceded by VALU/VMEM instructions; exit status 1 when any is found.
+
+Two forms of the join are recognised.  (1) The labelled one: `s_and_saveexec_b64 S` + `s_cbranch_execz L`, block L restores
+S - in both kinds of listing.  (2) The fall-through one: the backend drops the skip branch of a short body, the join then
+has no label and only the compiler's own listing still shows where it starts (`; %bb.N:`), so this form is checked in .s
+files only: the Makefile keeps the device assembly of every object (-save-temps; same code, compared once) for it.
 """
 import os
 import re
@@ -89,6 +94,63 @@ def check(path):
     return found
 
 
+MBB = re.compile(r"^; %bb\.\d+:")
+BRANCH_ON_EXEC = re.compile(r"^\s*s_cbranch_exec(z|nz)\b")
+RESTORE_ANY = re.compile(r"^\s*s_or_b64\s+exec,\s*exec,\s*(s\[\d+:\d+\])")
+
+
+def check_fallthrough(path):
+    """Form (2), compiler listings only: `s_and_saveexec_b64 S`, a body block without a skip branch or labels, then the join
+    block `; %bb.J:` that restores S.  -> the same tuples as check()."""
+    found = []
+    func = "?"
+    stage, sreg, join_at, pending = None, None, None, []
+    with open(path, errors="replace") as f:
+        for ln, raw in enumerate(f, 1):
+            if MBB.match(raw):
+                if stage == "saved":
+                    stage = "body"
+                elif stage == "body":
+                    stage, join_at, pending = "join", ln, []
+                else:
+                    stage = None
+                continue
+            line = raw.split(";")[0].rstrip()
+            if not line.strip() or line.lstrip().startswith("."):
+                name = label_of(line)
+                if name is not None:
+                    stage = None          # a label: not the simple fall-through shape
+                continue
+            name = label_of(line)
+            if name is not None:
+                if not BLOCK.match(name):
+                    func = name
+                stage = None
+                continue
+            m = SAVE.search(line)
+            if m:
+                stage, sreg = "saved", m.group(1)
+                continue
+            if stage == "saved":
+                stage = None              # a skip branch (form 1) or anything else between the save and the body
+                continue
+            if stage == "body":
+                if ENDS.match(line) or RESTORE_ANY.match(line):
+                    stage = None          # body and join in one block, or control flow inside the body
+                continue
+            if stage == "join":
+                r = RESTORE_ANY.match(line)
+                if r:
+                    if r.group(1) == sreg and pending:
+                        found.append((func, "(fall-through join)", join_at, pending))
+                    stage = None
+                elif VECTOR.match(line) and not EXEC_FREE.match(line):
+                    pending.append((ln, line.strip()))
+                elif ENDS.match(line) or re.search(r"\bexec\b", line):
+                    stage = None
+    return found
+
+
 LLVM_BIN = os.environ.get("LLVM_BIN", "/opt/rocm/lib/llvm/bin")
 
 
@@ -126,7 +188,7 @@ def main(argv):
                 text = os.path.join(d, "isa.s")
                 hits = check(text) if disassemble(path, text) else []
         else:
-            hits = check(path)
+            hits = check(path) + check_fallthrough(path)
         for func, label, ln, ins in hits:
             total += 1
             print(f"{path}:{ln}: {func[:90]} block {label}: {len(ins)} vector instruction(s) before the EXEC restore")
