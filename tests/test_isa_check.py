@@ -113,6 +113,37 @@ def test_join_without_a_skip_branch_is_checked_in_compiler_listings(tmp_path):
     assert isa_check.main([str(p)]) == 0
 
 
+ELSE_HEAD_S = """
+_Z6kernelv:
+	s_and_saveexec_b64 s[0:1], s[36:37]
+	s_xor_b64 s[36:37], exec, s[0:1]
+	s_cbranch_execz .LBB0_4
+; %bb.1:
+	v_add_u32_e32 v1, v2, v3
+.LBB0_4:
+	HEAD
+	s_or_saveexec_b64 s[0:1], s[36:37]
+	v_mov_b64_e32 v[0:1], s[2:3]
+	s_xor_b64 exec, exec, s[0:1]
+	s_cbranch_execz .LBB0_9
+; %bb.5:
+	v_add_u32_e32 v1, v2, v3
+.LBB0_9:
+	s_or_b64 exec, exec, s[0:1]
+	s_endpgm
+.Lfunc_end0:
+"""
+
+
+def test_else_block_head(tmp_path):
+    """if / else: the skip branch lands on the else block, whose prologue is `s_or_saveexec_b64 T, <flipped mask>` ...
+    `s_xor_b64 exec, exec, T`.  Copies BETWEEN the two are the backend's design (they run for the lanes of both sides);
+    a vector instruction ahead of the `s_or_saveexec_b64` runs under the then-side's mask only."""
+    assert run_on(tmp_path, ELSE_HEAD_S.replace("HEAD", "s_nop 0")) == []
+    hits = run_on(tmp_path, ELSE_HEAD_S.replace("HEAD", "v_mov_b32_e32 v7, v9"))
+    assert len(hits) == 1 and hits[0][1] == ".LBB0_4" and hits[0][3][0][1] == "v_mov_b32_e32 v7, v9"
+
+
 def test_objdump_listing_with_per_function_labels(tmp_path):
     hits = run_on(tmp_path, BAD_OBJDUMP)
     assert len(hits) == 1 and hits[0][1] == "L7"

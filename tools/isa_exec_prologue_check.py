@@ -15,8 +15,10 @@ source, so the build is checked instead:
 
 Reports every join block whose restore is preceded by VALU/VMEM instructions; exit status 1 when any is found.
 
-Two forms of the join are recognised.  (1) The labelled one: `s_and_saveexec_b64 S` + `s_cbranch_execz L`, block L restores
-S - in both kinds of listing.  (2) The fall-through one: the backend drops the skip branch of a short body, the join then
+Two forms of the join are recognised.  (1) The labelled one: `s_and_saveexec_b64 S` (+ `s_xor_b64 S2, exec, S` of an
+if / else) + `s_cbranch_execz L`; block L sets EXEC from S (`s_or_b64 exec, exec, S`) or, as the head of the else block, from
+S2 (`s_or_saveexec_b64 T, S2` - what stands between that and the following `s_xor_b64 exec, exec, T` runs for the lanes of
+both sides by the backend's design and is not flagged) - in both kinds of listing.  (2) The fall-through one: the backend drops the skip branch of a short body, the join then
 has no label and only the compiler's own listing still shows where it starts (`; %bb.N:`), so this form is checked in .s
 files only: the Makefile keeps the device assembly of every object (-save-temps; same code, compared once) for it.
 """
@@ -30,6 +32,7 @@ LABEL = re.compile(r"^(?:[0-9a-f]{8,16} <([^>]+)>|(\.LBB\d+_\d+|_Z\w+|[A-Za-z_]\
 SAVE = re.compile(r"\bs_and_saveexec_b64\s+(s\[\d+:\d+\])")
 SKIP = re.compile(r"\bs_cbranch_execz\s+(\.LBB\d+_\d+|L\d+)\b")
 BLOCK = re.compile(r"^(\.L\w+|L\d+)$")
+FLIP = re.compile(r"\bs_xor_b64\s+(s\[\d+:\d+\]),\s*exec,\s*(s\[\d+:\d+\])")
 VECTOR = re.compile(r"^\s*(v_|global_|flat_|scratch_|buffer_|ds_)")
 ENDS = re.compile(r"^\s*(s_cbranch|s_branch|s_endpgm|s_setpc|s_swappc)")
 # vector instructions that do not depend on EXEC are harmless ahead of the restore
@@ -49,6 +52,21 @@ def label_of(line):
     return (m.group(1) or m.group(2)) if m else None
 
 
+EXEC_WRITE = re.compile(r"^\s*s_(?:or|andn2|xor|mov|and)(_saveexec)?_b64\s+(.*)$")
+
+
+def writes_exec_from(line, saved):
+    """The instruction that ends a join's prologue: it sets EXEC from one of the saved masks - `s_or_b64 exec, exec, S` at
+    the end of an if, `s_or_saveexec_b64 T, S` / `s_andn2_saveexec_b64 T, S` at the head of an else block."""
+    m = EXEC_WRITE.match(line)
+    if not m:
+        return False
+    ops = [o.strip() for o in m.group(2).split(",")]
+    if not (m.group(1) or ops[0] == "exec"):
+        return False
+    return any(o in saved for o in ops[1:])
+
+
 def check(path):
     """-> [(function, label, line, [(line, text), ...])]"""
     lines = list(instructions(path))
@@ -62,10 +80,15 @@ def check(path):
         m = SAVE.search(line)
         if not m:
             continue
+        masks = {m.group(1)}
         for _, nxt in lines[i + 1:i + 4]:
+            x = FLIP.search(nxt)
+            if x and x.group(2) in masks:
+                masks.add(x.group(1))     # if / else: the else block restores from the flipped mask
+                continue
             k = SKIP.search(nxt)
             if k:
-                joins.setdefault((func, k.group(1)), set()).add(m.group(1))
+                joins.setdefault((func, k.group(1)), set()).update(masks)
                 break
             if label_of(nxt) is not None or VECTOR.match(nxt):
                 break
@@ -80,12 +103,12 @@ def check(path):
             continue
         if (func, name) not in joins:
             continue
-        restores = [re.compile(r"\bs_or_b64\s+exec,\s*exec,\s*" + re.escape(sg)) for sg in joins[(func, name)]]
+        saved = joins[(func, name)]
         pending = []
         for l2, t in lines[i + 1:]:
             if label_of(t) is not None or ENDS.match(t):
                 break                    # no restore in this block: the mask is restored further on (nested joins)
-            if any(r.search(t) for r in restores):
+            if writes_exec_from(t, saved):
                 if pending:
                     found.append((func, name, ln, pending))
                 break
