@@ -144,6 +144,35 @@ def test_else_block_head(tmp_path):
     assert len(hits) == 1 and hits[0][1] == ".LBB0_4" and hits[0][3][0][1] == "v_mov_b32_e32 v7, v9"
 
 
+LOOP_S = """
+_Z6kernelv:
+	s_mov_b64 s[14:15], 0
+.LBB0_1:
+	v_add_u32_e32 v1, v2, v3
+	v_cmp_gt_u32_e32 vcc, 2, v1
+	s_or_b64 s[14:15], vcc, s[14:15]
+	s_andn2_b64 exec, exec, s[14:15]
+	BRANCH
+	EXITHEAD
+	s_or_b64 exec, exec, s[14:15]
+	v_add_u32_e32 v1, v2, v3
+	s_endpgm
+.Lfunc_end0:
+"""
+
+
+@pytest.mark.parametrize("branch,exit_label", [("s_cbranch_execnz .LBB0_1\n; %bb.2:", ""),
+                                               ("s_cbranch_execz .LBB0_3\n\ts_branch .LBB0_1\n.LBB0_3:", ".LBB0_3")])
+def test_exit_of_a_divergent_loop(tmp_path, branch, exit_label):
+    """Lanes leave a divergent loop by clearing their EXEC bit: the exit block runs with EXEC = 0 until it restores them
+    from the break mask, so a vector copy ahead of that restore never executes."""
+    text = LOOP_S.replace("BRANCH", branch)
+    assert run_on(tmp_path, text.replace("EXITHEAD", "s_mov_b32 s3, 0")) == []
+    hits = run_on(tmp_path, text.replace("EXITHEAD", "v_mov_b32_e32 v9, v1"))
+    assert len(hits) == 1 and hits[0][3][0][1] == "v_mov_b32_e32 v9, v1"
+    assert hits[0][1] == (exit_label or "(loop exit)")
+
+
 def test_objdump_listing_with_per_function_labels(tmp_path):
     hits = run_on(tmp_path, BAD_OBJDUMP)
     assert len(hits) == 1 and hits[0][1] == "L7"

@@ -18,7 +18,10 @@ Reports every join block whose restore is preceded by VALU/VMEM instructions; ex
 Two forms of the join are recognised.  (1) The labelled one: `s_and_saveexec_b64 S` (+ `s_xor_b64 S2, exec, S` of an
 if / else) + `s_cbranch_execz L`; block L sets EXEC from S (`s_or_b64 exec, exec, S`) or, as the head of the else block, from
 S2 (`s_or_saveexec_b64 T, S2` - what stands between that and the following `s_xor_b64 exec, exec, T` runs for the lanes of
-both sides by the backend's design and is not flagged) - in both kinds of listing.  (2) The fall-through one: the backend drops the skip branch of a short body, the join then
+both sides by the backend's design and is not flagged) - in both kinds of listing.  The exit of a divergent loop
+(`s_andn2_b64 exec, exec, B` + a branch on EXEC) is the same thing with the break mask B: the block the loop leaves to -
+the target of a forward `s_cbranch_execz`, or what follows the backward `s_cbranch_execnz` - runs with EXEC = 0 until its
+`s_or_b64 exec, exec, B`.  (2) The fall-through one: the backend drops the skip branch of a short body, the join then
 has no label and only the compiler's own listing still shows where it starts (`; %bb.N:`), so this form is checked in .s
 files only: the Makefile keeps the device assembly of every object (-save-temps; same code, compared once) for it.
 """
@@ -32,6 +35,8 @@ LABEL = re.compile(r"^(?:[0-9a-f]{8,16} <([^>]+)>|(\.LBB\d+_\d+|_Z\w+|[A-Za-z_]\
 SAVE = re.compile(r"\bs_and_saveexec_b64\s+(s\[\d+:\d+\])")
 SKIP = re.compile(r"\bs_cbranch_execz\s+(\.LBB\d+_\d+|L\d+)\b")
 BLOCK = re.compile(r"^(\.L\w+|L\d+)$")
+LOOP_MASK = re.compile(r"\bs_andn2_b64\s+exec,\s*exec,\s*(s\[\d+:\d+\])")
+LOOP_BACK = re.compile(r"\bs_cbranch_execnz\s+(\.LBB\d+_\d+|L\d+)\b")
 FLIP = re.compile(r"\bs_xor_b64\s+(s\[\d+:\d+\]),\s*exec,\s*(s\[\d+:\d+\])")
 VECTOR = re.compile(r"^\s*(v_|global_|flat_|scratch_|buffer_|ds_)")
 ENDS = re.compile(r"^\s*(s_cbranch|s_branch|s_endpgm|s_setpc|s_swappc)")
@@ -72,11 +77,26 @@ def check(path):
     lines = list(instructions(path))
     # the skip branch of every divergent if: (function, label) -> the SGPR pairs holding the mask to restore there
     joins = {}
+    fallouts = []          # (function, index of the backward branch, break mask)
     func = "?"
     for i, (ln, line) in enumerate(lines):
         name = label_of(line)
         if name is not None and not BLOCK.match(name):
             func = name
+        lp = LOOP_MASK.search(line)
+        if lp:
+            # a divergent loop: lanes leave by clearing their EXEC bit; the exit block restores them all from the break mask
+            for j, (_, nxt) in enumerate(lines[i + 1:i + 4]):
+                k = SKIP.search(nxt)
+                if k:                                   # exit by a forward skip: the labelled block restores
+                    joins.setdefault((func, k.group(1)), set()).add(lp.group(1))
+                    break
+                if LOOP_BACK.search(nxt):               # exit by falling out of the backward branch
+                    fallouts.append((func, i + 1 + j, lp.group(1)))
+                    break
+                if label_of(nxt) is not None or VECTOR.match(nxt):
+                    break
+            continue
         m = SAVE.search(line)
         if not m:
             continue
@@ -93,6 +113,23 @@ def check(path):
             if label_of(nxt) is not None or VECTOR.match(nxt):
                 break
     found = []
+    for func, at, mask in fallouts:
+        pending = []
+        for l2, t in lines[at + 1:]:
+            if label_of(t) is not None and not BLOCK.match(label_of(t)):
+                break
+            if label_of(t) is not None:
+                continue                 # the exit block may carry a label of its own
+            if ENDS.match(t):
+                break
+            if writes_exec_from(t, {mask}):
+                if pending:
+                    found.append((func, "(loop exit)", lines[at][0], pending))
+                break
+            if VECTOR.match(t) and not EXEC_FREE.match(t):
+                pending.append((l2, t.strip()))
+            elif re.search(r"\bexec\b", t):
+                break
     func = "?"
     for i, (ln, line) in enumerate(lines):
         name = label_of(line)
